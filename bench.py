@@ -1,0 +1,204 @@
+#!/usr/bin/env python3
+"""Headline benchmark: STFT Msamples/s at FFT 1024, Hann, 75 % overlap (hop 256) on MI355X.
+
+Workload (BASELINE.json configs[1]): one hour of synthetic 384 kHz mono bat-call PCM per GPU,
+resident in HBM before the timed region; one step = one pass of the worker-path transform
+(spectrogramWorker.js semantics: worker Hann, accurate twiddles, log10|X|/5 quantiser) over the
+whole recording.  Ranks are independent (one recording each, no collective in the data path).
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--out u8|rgba] [--seconds S]
+
+Prints ONE JSON line (rank 0).  `value` is whole-job Msamples/s.  `roofline` prices the dominant
+kernel against HBM with algorithmic bytes (each input sample once + each output byte once) over
+its average launch time measured with HIP events on the launch stream.  `cpu_baseline` is the CPU
+checker in oracle/ (a C restatement of the reference's worker) timed on the host cores on a bounded
+sample of the same signal.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+SAMPLE_RATE = 384000
+FFT_N = 1024
+HOP = 256
+HBM_PEAK_GBS = 8000.0
+
+
+def synth_chunk(torch, dev, start, count, seed):
+    """Bat-call-like PCM on the device: white noise 0.01 + 5 ms FM down-sweeps (80->35 kHz, Hann
+    envelope, amplitude 0.3) every 80 ms + a 110 kHz CF tone (0.05) in the second half of each
+    10 s block.  float32 in [-1, 1]."""
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    i = torch.arange(start, start + count, device=dev, dtype=torch.float64)
+    x = 0.01 * (2 * torch.rand(count, device=dev, generator=g, dtype=torch.float32) - 1)
+    period, plen = int(0.080 * SAMPLE_RATE), int(0.005 * SAMPLE_RATE)
+    p = torch.remainder(i, period)
+    t = p / SAMPLE_RATE
+    dur = plen / SAMPLE_RATE
+    phase = 2 * np.pi * (80000.0 * t + 0.5 * (35000.0 - 80000.0) * t * t / dur)
+    env = 0.5 * (1 - torch.cos(2 * np.pi * p / plen))
+    pulse = (0.3 * env * torch.sin(phase)).to(torch.float32)
+    x += torch.where(p < plen, pulse, torch.zeros_like(pulse))
+    block = torch.remainder(i, 10 * SAMPLE_RATE)
+    cf = (0.05 * torch.sin(2 * np.pi * 110000.0 * i / SAMPLE_RATE)).to(torch.float32)
+    x += torch.where(block >= 5 * SAMPLE_RATE, cf, torch.zeros_like(cf))
+    return x
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--out", choices=["u8", "rgba"], default="u8")
+    ap.add_argument("--seconds", type=int, default=3600, help="recording length per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-variants", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            print("bench.py: --gpus %d needs torch.distributed.run with %d ranks" % (args.gpus, args.gpus), file=sys.stderr)
+            sys.exit(2)
+
+    import torch
+    import torch.distributed as dist
+
+    from spectrogram_amd import _ffi as F
+    from spectrogram_amd import engine as E
+
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    L = args.seconds * SAMPLE_RATE
+    # ---- synthetic recording, generated on the device in 10 s blocks
+    x = torch.empty(L, dtype=torch.float32, device=dev)
+    blk = 10 * SAMPLE_RATE
+    for s in range(0, L, blk):
+        c = min(blk, L - s)
+        x[s:s + c] = synth_chunk(torch, dev, s, c, 12345 + rank * 1000 + s // blk)
+    torch.cuda.synchronize()
+
+    def make_engine(out_kind):
+        eng = E.Engine(fft_n=FFT_N, hop=HOP, window_id=F.WIN_WORKER_HANN, scale_mode=F.SCALE_WORKER_LOG5,
+                       frame_rule=F.FRAMES_WORKER_COMPAT, twiddle_mode=F.TW_ACCURATE, arith=F.ARITH_FAST_F32,
+                       out_kind=out_kind, device=local_rank)
+        eng.set_stream(torch.cuda.current_stream().cuda_stream)
+        return eng
+
+    def run(out_name, steps, warmup):
+        kind = F.OUT_U8_INDEX if out_name == "u8" else F.OUT_RGBA8
+        eng = make_engine(kind)
+        nbytes = eng.out_bytes(L)
+        out = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        g = eng.geometry(L)
+        for _ in range(warmup):
+            eng.stft_device(x.data_ptr(), L, out.data_ptr(), nbytes, wait=False)
+        barrier()
+        t0 = time.perf_counter()
+        eng.timer_start()
+        for _ in range(steps):
+            eng.stft_device(x.data_ptr(), L, out.data_ptr(), nbytes, wait=False)
+        ev_ms = eng.timer_stop_ms()          # HIP events on the launch stream
+        barrier()
+        wall = time.perf_counter() - t0
+        checksum = int(out[: 1 << 20].to(torch.int64).sum().item())
+        eng.close()
+        del out
+        return wall, ev_ms / steps, nbytes, g, checksum
+
+    wall, kern_ms, out_bytes, geo, checksum = run(args.out, args.steps, args.warmup)
+    if world > 1:
+        t = torch.tensor([wall], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        wall = float(t.item())
+    value = world * L * args.steps / wall / 1e6
+
+    result = None
+    if rank == 0:
+        algo_bytes = L * 4 + out_bytes
+        achieved = algo_bytes / (kern_ms * 1e-3) / 1e9
+        result = {
+            "metric": "STFT Msamples/s at FFT 1024 Hann 75% overlap",
+            "value": round(value, 1),
+            "unit": "Msamples/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(wall / args.steps * 1e3, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": "%d s x 384 kHz mono synthetic bat-call PCM per GPU, FFT 1024, worker Hann, hop 256 (75%% overlap), "
+                            "worker log10|X|/5 quantiser, output %s" % (args.seconds, "uint8 index [frame][bin]" if args.out == "u8"
+                                                                        else "RGBA8 image [bin][frame]"),
+                "samples_per_gpu": L, "frames_per_gpu": int(geo.frames), "fft": FFT_N, "hop": HOP,
+                "sharding": "one recording per GPU, no collective",
+            },
+            "roofline": {
+                "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "kernel_ms": round(kern_ms, 4), "algorithmic_bytes_per_launch": int(algo_bytes),
+                "bytes_per_sample": round(algo_bytes / L, 3),
+            },
+            "checksum": checksum,
+        }
+
+    if rank == 0 and world == 1 and not args.no_variants:
+        other = "rgba" if args.out == "u8" else "u8"
+        w2, k2, ob2, _, _ = run(other, max(3, args.steps // 4), 1)
+        result["variants"] = {
+            other: {"value": round(L * max(3, args.steps // 4) / w2 / 1e6, 1), "kernel_ms": round(k2, 4),
+                    "roofline_frac": round((L * 4 + ob2) / (k2 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+        }
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        import oracle
+        cores = min(16, len(os.sched_getaffinity(0)))
+        probe = x[: 2 * SAMPLE_RATE].cpu().numpy()
+        t0 = time.perf_counter()
+        oracle.worker_render(probe, FFT_N, 75.0, None, threads=cores)
+        rate = len(probe) / (time.perf_counter() - t0)            # samples/s on `cores` threads
+        secs = int(max(4, min(120, rate * 12 / SAMPLE_RATE)))       # about 12 s of CPU work
+        sample = x[: secs * SAMPLE_RATE].cpu().numpy()
+        t0 = time.perf_counter()
+        oracle.worker_render(sample, FFT_N, 75.0, None, threads=cores)
+        dt = time.perf_counter() - t0
+        result["cpu_baseline"] = {
+            "value": round(len(sample) / dt / 1e6, 2), "unit": "Msamples/s", "cores": cores, "kind": "port",
+            "sample": "first %d s of the same recording (%d samples), RGBA render by the C restatement of "
+                      "spectrogramWorker.js (oracle/), %d POSIX threads" % (secs, len(sample), cores),
+            "seconds": round(dt, 2),
+        }
+
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(result))
+
+
+if __name__ == "__main__":
+    main()

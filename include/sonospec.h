@@ -1,0 +1,226 @@
+/*
+ * sonospec.h -- C ABI of libsonospec.so, the MI355X (gfx950) spectrogram engine.
+ *
+ * The library replaces, for batch processing, the two JavaScript spectrogram paths of the
+ * SonoRadar viewer.  Each entry point names the reference code it stands in for (file:line in
+ * the reference tree); a binding (N-API, ctypes, ...) needs nothing but this header.
+ *
+ *   worker path   spectrogramWorker.js:38-99,206-253     Hann STFT -> log10(|X|)/5 -> RGBA image
+ *   plugin path   modules/spectrogram.esm.js:95-201      windowed FFT with recurrence twiddles
+ *                 modules/spectrogram.esm.js:492-542     getFrequencies: dB/gain/range -> uint8
+ *                 modules/spectrogram.esm.js:595-640     resample to pixel columns
+ *                 modules/spectrogram.esm.js:345-388     colour LUT, vertical flip, band crop
+ *
+ * Conventions: every function returns SONO_OK (0) or a negative sono_status; the text of the
+ * last failure on a context is available from sono_last_error().  The caller owns every buffer
+ * it passes.  A context belongs to one thread and one GPU; contexts are independent.  No C++
+ * types, exceptions or framework objects cross this boundary.
+ */
+#ifndef SONOSPEC_H
+#define SONOSPEC_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SONOSPEC_ABI_VERSION 1
+
+typedef struct sono_ctx sono_ctx;
+
+typedef enum sono_status {
+  SONO_OK = 0,
+  SONO_ERR_ARG = -1,       /* bad argument (size, enum, NULL)                         */
+  SONO_ERR_WINDOW = -2,    /* "No such window function" (spectrogram.esm.js:149-150)   */
+  SONO_ERR_FFT_SIZE = -3,  /* "Invalid buffer size, must be a power of 2." (:168-169)  */
+  SONO_ERR_COLORMAP = -4,  /* colour map validation (:213-217)                         */
+  SONO_ERR_CAPACITY = -5,  /* output buffer too small                                  */
+  SONO_ERR_DEVICE = -6,    /* HIP runtime error, text in sono_last_error               */
+  SONO_ERR_NO_DEVICE = -7  /* no usable GPU                                            */
+} sono_status;
+
+/* Window functions in the order of the plugin's switch, spectrogram.esm.js:105-151. */
+typedef enum sono_window {
+  SONO_WIN_BARTLETT = 0,
+  SONO_WIN_BARTLETT_HANN = 1,
+  SONO_WIN_BLACKMAN = 2,
+  SONO_WIN_COSINE = 3,
+  SONO_WIN_GAUSS = 4,
+  SONO_WIN_HAMMING = 5,
+  SONO_WIN_HANN = 6,
+  SONO_WIN_LANCZOZ = 7,
+  SONO_WIN_RECTANGULAR = 8,
+  SONO_WIN_TRIANGULAR = 9,
+  SONO_WIN_WORKER_HANN = 10 /* the worker's own Hann table, spectrogramWorker.js:195-203 */
+} sono_window;
+
+/* Which quantiser turns |X| into a colour index. */
+typedef enum sono_scale_mode {
+  SONO_SCALE_WORKER_LOG5 = 0, /* floor(255*clamp(log10|X|/5,0,1)), spectrogramWorker.js:71-78  */
+  SONO_SCALE_PLUGIN_DB = 1    /* 20*log10(2/N*|X|) with gainDB/rangeDB, spectrogram.esm.js:531-535 */
+} sono_scale_mode;
+
+/* Which frames exist for a signal of L samples. */
+typedef enum sono_frame_rule {
+  SONO_FRAMES_PLUGIN_STRICT = 0, /* a + N <  L : ceil((L-N)/hop) frames, spectrogram.esm.js:526 */
+  SONO_FRAMES_WORKER_COMPAT = 1  /* a + N <= L, image ceil((L-N)/hop) wide; a frame past the
+                                    image lands in column 0 one row down, spectrogramWorker.js:40,59,79 */
+} sono_frame_rule;
+
+/* Where the FFT's twiddle factors come from. */
+typedef enum sono_twiddle_mode {
+  SONO_TW_ACCURATE = 0,          /* cos/sin(-2*pi*j/n2) per stage, spectrogramWorker.js:110-125 */
+  SONO_TW_PLUGIN_RECURRENCE = 1, /* running product seeded with float32 cos/sin(-pi/T),
+                                    spectrogram.esm.js:158-160,176-190                          */
+  SONO_TW_HOST_TABLE = 2         /* supplied through sono_set_tables                            */
+} sono_twiddle_mode;
+
+typedef enum sono_arith {
+  SONO_ARITH_FAST_F32 = 0, /* float32 kernels; dB within 0.01 dB, indices within 1 LSB          */
+  SONO_ARITH_EXACT_F64 = 1 /* the reference's radix-2 dataflow in double with a float32 rounding
+                              at every store, no FMA: magnitudes bit-identical to the JavaScript */
+} sono_arith;
+
+typedef enum sono_out_kind {
+  SONO_OUT_U8_INDEX = 0, /* [frame][bin] uint8, bin 0 = DC (getFrequencies layout)               */
+  SONO_OUT_RGBA8 = 1,    /* [row][column] RGBA8, row 0 = highest bin, column = frame
+                            (ImageData layout of the worker and of drawSpectrogram)              */
+  SONO_OUT_F32_DB = 2,   /* [frame][bin] float32 20*log10(m), m = |X| (worker) or 2/N*|X| (plugin) */
+  SONO_OUT_F32_MAG = 3   /* [frame][bin] float32 m                                               */
+} sono_out_kind;
+
+typedef enum sono_in_kind {
+  SONO_IN_F32 = 0, /* float32 samples in [-1,1]                       */
+  SONO_IN_I16 = 1  /* int16 PCM; sample value = s / 32768 (exact)      */
+} sono_in_kind;
+
+typedef enum sono_mem { SONO_MEM_HOST = 0, SONO_MEM_DEVICE = 1 } sono_mem;
+
+typedef struct sono_config {
+  uint32_t fft_n;        /* fftSamples / fftSize: power of two, 64 ... 8192                     */
+  uint32_t hop;          /* fft_n - noverlap (plugin) or the worker's hop; >= 1                 */
+  uint32_t window_id;    /* sono_window                                                         */
+  uint32_t scale_mode;   /* sono_scale_mode                                                     */
+  uint32_t frame_rule;   /* sono_frame_rule                                                     */
+  uint32_t twiddle_mode; /* sono_twiddle_mode                                                   */
+  uint32_t arith;        /* sono_arith                                                          */
+  uint32_t out_kind;     /* sono_out_kind                                                       */
+  uint32_t in_kind;      /* sono_in_kind                                                        */
+  uint32_t bin_lo;       /* first bin kept (band crop); 0 = DC                                  */
+  uint32_t bin_hi;       /* one past the last bin kept; 0 means fft_n/2                         */
+  uint32_t reserved0;    /* must be zero                                                        */
+  double alpha;          /* blackman / gauss parameter; <= 0 or NaN selects the reference default */
+  double gain_db;        /* plugin quantiser gainDB (reference default 20)                      */
+  double range_db;       /* plugin quantiser rangeDB (reference default 80); must be > 0        */
+  uint32_t reserved[4];  /* must be zero                                                        */
+} sono_config;
+
+typedef struct sono_geometry {
+  uint64_t frames; /* frames the transform computes                                              */
+  uint64_t width;  /* image columns (differs from frames only under SONO_FRAMES_WORKER_COMPAT)   */
+  uint32_t bins;   /* bin_hi - bin_lo: uint8 row length / image height                           */
+  uint32_t hop;
+} sono_geometry;
+
+/* ---- library / device ----------------------------------------------------------------- */
+
+int sono_abi_version(void);
+/* Number of GPUs the process can use; 0 when there is none (never an error). */
+int sono_device_count(void);
+
+/* ---- host-side rules (no GPU needed) ---------------------------------------------------- */
+
+/* Worker hop: max(1, floor(N*(1-pct/100))), spectrogramWorker.js:39. */
+uint32_t sono_worker_hop(uint32_t fft_n, double overlap_pct);
+/* Plugin overlap: noverlap if > 0, else max(0, round(N - L/canvas_width)), spectrogram.esm.js:502-506. */
+uint32_t sono_plugin_noverlap(uint32_t fft_n, uint32_t noverlap, uint64_t n_samples, uint32_t canvas_width);
+/* wsManager's percent rule: floor(N * pct / 100), modules/wsManager.js:87-89. */
+uint32_t sono_overlap_from_percent(uint32_t fft_n, double overlap_pct);
+/* Frame count / image width for a signal length under a frame rule. */
+int sono_geometry_for(uint32_t fft_n, uint32_t hop, uint32_t frame_rule, uint32_t bin_lo, uint32_t bin_hi,
+                      uint64_t n_samples, sono_geometry* out);
+/* Source-row window of drawSpectrogram for scale 'linear' (spectrogram.esm.js:353-355,377-380):
+ * rows [sy, sy+sh) of the flipped image, i.e. bins [bins-sy-sh, bins-sy).  fmax_hz == 0 = Nyquist. */
+int sono_plugin_crop(uint32_t bins, double sample_rate, double fmin_hz, double fmax_hz, int64_t* sy, int64_t* sh);
+/* Colour LUTs: 256 RGBA doubles -> 1024 bytes.  Plugin rule spectrogram.esm.js:262-271, worker
+ * rule spectrogramWorker.js:128-143 (NaN channel = absent). */
+int sono_plugin_lut(const double* colormap_rgba, uint8_t* lut_rgba);
+int sono_worker_lut(const double* colormap_rgba, uint8_t* lut_rgba);
+/* Window table exactly as the reference fills it (float32).  SONO_ERR_WINDOW for an unknown id. */
+int sono_window_table(uint32_t window_id, uint32_t fft_n, double alpha, float* out);
+/* Twiddle table in the flat stage layout: the stage with half size T occupies [T-1, 2T-1). */
+int sono_twiddle_table(uint32_t twiddle_mode, uint32_t fft_n, double* cos_out, double* sin_out);
+
+/* ---- context ------------------------------------------------------------------------------ */
+
+/* Replaces `new FFT(...)` + the per-render set-up of both paths (spectrogram.esm.js:507,
+ * spectrogramWorker.js:46-57).  Builds window and twiddle tables on the host and uploads them.
+ * Returns NULL on failure; sono_create_error() then holds the reason. */
+sono_ctx* sono_create(int device, const sono_config* cfg);
+const char* sono_create_error(void);
+void sono_destroy(sono_ctx* ctx);
+const char* sono_last_error(const sono_ctx* ctx);
+int sono_get_config(const sono_ctx* ctx, sono_config* out);
+
+/* Launch on a caller-owned HIP stream (hipStream_t passed as void*); NULL restores the
+ * context's own stream. */
+int sono_set_stream(sono_ctx* ctx, void* hip_stream);
+
+/* Colour LUT used by SONO_OUT_RGBA8 and sono_colorize (what _colorMapUint / colorMapUint hold,
+ * spectrogram.esm.js:262-271, spectrogramWorker.js:128-143).  NULL selects the worker's grey
+ * fallback (col,col,col,255), spectrogramWorker.js:88-93. */
+int sono_set_colormap(sono_ctx* ctx, const uint8_t* lut_rgba /* 1024 bytes or NULL */);
+
+/* Host-computed tables (a JavaScript host passes the ones its own Math.cos/sin produced so the
+ * exact mode sees V8's values).  Either pointer may be NULL to keep the current table. */
+int sono_set_tables(sono_ctx* ctx, const float* window /* fft_n */, const double* tw_cos, const double* tw_sin /* fft_n-1 each */);
+
+/* ---- the transform ------------------------------------------------------------------------ */
+
+int sono_geometry_of(const sono_ctx* ctx, uint64_t n_samples, sono_geometry* out);
+/* Bytes sono_stft writes for n_samples under the context's out_kind. */
+uint64_t sono_out_bytes(const sono_ctx* ctx, uint64_t n_samples);
+
+/* One recording (or one hop-aligned chunk of one): PCM -> out_kind.  Replaces
+ * renderSpectrogram (spectrogramWorker.js:38-99) and getFrequencies (spectrogram.esm.js:492-542).
+ * `mem` tells whether pcm/out are host or device pointers (sono_mem); host buffers are staged
+ * through context-owned device memory.  Synchronous: the result is complete on return. */
+int sono_stft(sono_ctx* ctx, const void* pcm, uint64_t n_samples, void* out, uint64_t out_capacity_bytes, int mem);
+
+/* Same, device pointers only, enqueued on the context's stream without waiting. */
+int sono_stft_async(sono_ctx* ctx, const void* pcm_dev, uint64_t n_samples, void* out_dev, uint64_t out_capacity_bytes);
+int sono_wait(sono_ctx* ctx);
+
+/* resample (spectrogram.esm.js:595-640): [in_frames][bins] uint8 -> [out_width][bins] uint8. */
+int sono_resample(sono_ctx* ctx, const uint8_t* in, uint64_t in_frames, uint32_t bins, uint64_t out_width,
+                  uint8_t* out, int mem);
+
+/* LUT + vertical flip + row window of drawSpectrogram (spectrogram.esm.js:366-380):
+ * [width][bins] uint8 -> rows [row0, row0+rows) of the [bins][width] RGBA image. */
+int sono_colorize(sono_ctx* ctx, const uint8_t* frames, uint64_t width, uint32_t bins, uint32_t row0,
+                  uint32_t rows, uint8_t* rgba, int mem);
+
+/* Per-frame peak over the kept band of a [frames][bins] uint8 index matrix: first bin holding
+ * the maximum (the strict-> rule of spectrogram.esm.js:196) and that maximum. */
+int sono_frame_peaks(sono_ctx* ctx, const uint8_t* idx, uint64_t frames, uint32_t bins, int32_t* peak_bin,
+                     uint8_t* peak_idx, int mem);
+
+/* ---- device memory for hosts without an allocator of their own (N-API addon, C++ bench) ---- */
+
+void* sono_device_malloc(sono_ctx* ctx, uint64_t bytes);
+int sono_device_free(sono_ctx* ctx, void* p);
+int sono_copy_to_device(sono_ctx* ctx, void* dst_dev, const void* src_host, uint64_t bytes);
+int sono_copy_to_host(sono_ctx* ctx, void* dst_host, const void* src_dev, uint64_t bytes);
+
+/* ---- timing (HIP events on the context's stream) ------------------------------------------ */
+
+int sono_timer_start(sono_ctx* ctx);
+/* Records the stop event, waits for it and returns the elapsed milliseconds (< 0 on error). */
+double sono_timer_stop_ms(sono_ctx* ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SONOSPEC_H */

@@ -1,0 +1,506 @@
+// C ABI of libsonospec.so: context management, host staging and kernel dispatch.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "sono_internal.h"
+#include "sonospec.h"
+
+using namespace sono;
+
+struct sono_ctx {
+  int device = 0;
+  sono_config cfg{};
+  uint32_t bin_lo = 0, bin_hi = 0;
+  hipStream_t own_stream = nullptr;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+  // device tables
+  float* d_window = nullptr;
+  void* d_tw = nullptr;       // float2[n-1] (fast) or double2[n-1] (exact)
+  uint32_t* d_lut = nullptr;  // 256 packed pixels
+  bool have_lut = false;
+  // host copies (sono_set_tables may replace part of them)
+  std::vector<float> h_window;
+  std::vector<double> h_cos, h_sin;
+  // staging for host-pointer calls
+  void* d_in = nullptr;
+  uint64_t d_in_bytes = 0;
+  void* d_out = nullptr;
+  uint64_t d_out_bytes = 0;
+  void* d_aux = nullptr;
+  uint64_t d_aux_bytes = 0;
+  std::string err;
+};
+
+static thread_local std::string g_create_error;
+
+static int fail(sono_ctx* c, int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  if (c) c->err = buf; else g_create_error = buf;
+  return code;
+}
+
+#define HIP_TRY(c, expr)                                                                            \
+  do {                                                                                              \
+    hipError_t e_ = (expr);                                                                         \
+    if (e_ != hipSuccess) return fail((c), SONO_ERR_DEVICE, "%s: %s", #expr, hipGetErrorString(e_)); \
+  } while (0)
+
+static int ensure(sono_ctx* c, void** p, uint64_t* have, uint64_t need) {
+  if (*have >= need && *p) return SONO_OK;
+  if (*p) HIP_TRY(c, hipFree(*p));
+  *p = nullptr;
+  *have = 0;
+  const uint64_t want = need < 4096 ? 4096 : need;
+  HIP_TRY(c, hipMalloc(p, want));
+  *have = want;
+  return SONO_OK;
+}
+
+static int upload_tables(sono_ctx* c) {
+  const uint32_t n = c->cfg.fft_n;
+  HIP_TRY(c, hipMemcpyAsync(c->d_window, c->h_window.data(), sizeof(float) * n, hipMemcpyHostToDevice, c->stream));
+  if (c->cfg.arith == SONO_ARITH_EXACT_F64) {
+    std::vector<double> t(2 * (size_t)(n - 1));
+    for (uint32_t i = 0; i + 1 < n; i++) {
+      t[2 * i] = c->h_cos[i];
+      t[2 * i + 1] = c->h_sin[i];
+    }
+    HIP_TRY(c, hipMemcpyAsync(c->d_tw, t.data(), sizeof(double) * t.size(), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+  } else {
+    std::vector<float> t(2 * (size_t)(n - 1));
+    for (uint32_t i = 0; i + 1 < n; i++) {
+      t[2 * i] = (float)c->h_cos[i];
+      t[2 * i + 1] = (float)c->h_sin[i];
+    }
+    HIP_TRY(c, hipMemcpyAsync(c->d_tw, t.data(), sizeof(float) * t.size(), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+  }
+  return SONO_OK;
+}
+
+extern "C" {
+
+int sono_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) {
+    (void)hipGetLastError();
+    return 0;
+  }
+  return n;
+}
+
+const char* sono_create_error(void) { return g_create_error.c_str(); }
+
+sono_ctx* sono_create(int device, const sono_config* cfg) {
+  g_create_error.clear();
+  if (!cfg) {
+    fail(nullptr, SONO_ERR_ARG, "config is NULL");
+    return nullptr;
+  }
+  for (uint32_t r : {cfg->reserved0, cfg->reserved[0], cfg->reserved[1], cfg->reserved[2], cfg->reserved[3]})
+    if (r != 0) {
+      fail(nullptr, SONO_ERR_ARG, "reserved config fields must be zero");
+      return nullptr;
+    }
+  const uint32_t n = cfg->fft_n;
+  if (!is_pow2(n)) {
+    fail(nullptr, SONO_ERR_FFT_SIZE, "Invalid buffer size, must be a power of 2.");
+    return nullptr;
+  }
+  if (n < 64 || n > 8192) {
+    fail(nullptr, SONO_ERR_FFT_SIZE, "fft_n must be between 64 and 8192 (got %u)", n);
+    return nullptr;
+  }
+  if (cfg->hop == 0) {
+    fail(nullptr, SONO_ERR_ARG, "hop must be at least 1 (noverlap must be smaller than fftSamples)");
+    return nullptr;
+  }
+  if (cfg->scale_mode > SONO_SCALE_PLUGIN_DB || cfg->frame_rule > SONO_FRAMES_WORKER_COMPAT ||
+      cfg->twiddle_mode > SONO_TW_HOST_TABLE || cfg->arith > SONO_ARITH_EXACT_F64 || cfg->out_kind > SONO_OUT_F32_MAG ||
+      cfg->in_kind > SONO_IN_I16) {
+    fail(nullptr, SONO_ERR_ARG, "config enum out of range");
+    return nullptr;
+  }
+  if (cfg->scale_mode == SONO_SCALE_PLUGIN_DB && !(cfg->range_db > 0)) {
+    fail(nullptr, SONO_ERR_ARG, "range_db must be positive");
+    return nullptr;
+  }
+  sono_geometry g;
+  if (compute_geometry(n, cfg->hop, cfg->frame_rule, cfg->bin_lo, cfg->bin_hi, 0, &g) != SONO_OK) {
+    fail(nullptr, SONO_ERR_ARG, "bin window [%u, %u) is not inside [0, %u)", cfg->bin_lo, cfg->bin_hi, n / 2);
+    return nullptr;
+  }
+  std::vector<float> win(n);
+  if (fill_window(cfg->window_id, n, cfg->alpha, win.data()) != SONO_OK) {
+    fail(nullptr, SONO_ERR_WINDOW, "No such window function '%u'", cfg->window_id);
+    return nullptr;
+  }
+  int count = sono_device_count();
+  if (count <= 0) {
+    fail(nullptr, SONO_ERR_NO_DEVICE, "no HIP device available");
+    return nullptr;
+  }
+  if (device < 0 || device >= count) {
+    fail(nullptr, SONO_ERR_ARG, "device %d out of range (have %d)", device, count);
+    return nullptr;
+  }
+  sono_ctx* c = new (std::nothrow) sono_ctx();
+  if (!c) return nullptr;
+  c->device = device;
+  c->cfg = *cfg;
+  c->bin_lo = cfg->bin_lo;
+  c->bin_hi = cfg->bin_hi ? cfg->bin_hi : n / 2;
+  c->h_window = std::move(win);
+  c->h_cos.assign(n, 0.0);
+  c->h_sin.assign(n, 0.0);
+  if (cfg->twiddle_mode == SONO_TW_HOST_TABLE)
+    fill_twiddles(SONO_TW_ACCURATE, n, c->h_cos.data(), c->h_sin.data());  // until sono_set_tables replaces them
+  else
+    fill_twiddles(cfg->twiddle_mode, n, c->h_cos.data(), c->h_sin.data());
+
+  auto bail = [&](const char* what, hipError_t e) -> sono_ctx* {
+    fail(nullptr, SONO_ERR_DEVICE, "%s: %s", what, hipGetErrorString(e));
+    sono_destroy(c);
+    return nullptr;
+  };
+  hipError_t e;
+  if ((e = hipSetDevice(device)) != hipSuccess) return bail("hipSetDevice", e);
+  if ((e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
+  c->stream = c->own_stream;
+  if ((e = hipEventCreate(&c->ev_start)) != hipSuccess) return bail("hipEventCreate", e);
+  if ((e = hipEventCreate(&c->ev_stop)) != hipSuccess) return bail("hipEventCreate", e);
+  if ((e = hipMalloc((void**)&c->d_window, sizeof(float) * n)) != hipSuccess) return bail("hipMalloc(window)", e);
+  if ((e = hipMalloc(&c->d_tw, sizeof(double) * 2 * n)) != hipSuccess) return bail("hipMalloc(twiddles)", e);
+  if ((e = hipMalloc((void**)&c->d_lut, 1024)) != hipSuccess) return bail("hipMalloc(lut)", e);
+  if (upload_tables(c) != SONO_OK) {
+    g_create_error = c->err;
+    sono_destroy(c);
+    return nullptr;
+  }
+  return c;
+}
+
+void sono_destroy(sono_ctx* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
+  void* bufs[] = {c->d_window, c->d_tw, c->d_lut, c->d_in, c->d_out, c->d_aux};
+  for (void* b : bufs)
+    if (b) (void)hipFree(b);
+  if (c->ev_start) (void)hipEventDestroy(c->ev_start);
+  if (c->ev_stop) (void)hipEventDestroy(c->ev_stop);
+  if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+  delete c;
+}
+
+const char* sono_last_error(const sono_ctx* c) { return c ? c->err.c_str() : "context is NULL"; }
+
+int sono_get_config(const sono_ctx* c, sono_config* out) {
+  if (!c || !out) return SONO_ERR_ARG;
+  *out = c->cfg;
+  return SONO_OK;
+}
+
+int sono_set_stream(sono_ctx* c, void* s) {
+  if (!c) return SONO_ERR_ARG;
+  c->stream = s ? reinterpret_cast<hipStream_t>(s) : c->own_stream;
+  return SONO_OK;
+}
+
+int sono_set_colormap(sono_ctx* c, const uint8_t* lut) {
+  if (!c) return SONO_ERR_ARG;
+  HIP_TRY(c, hipSetDevice(c->device));
+  if (!lut) {
+    c->have_lut = false;
+    return SONO_OK;
+  }
+  HIP_TRY(c, hipMemcpyAsync(c->d_lut, lut, 1024, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  c->have_lut = true;
+  return SONO_OK;
+}
+
+int sono_set_tables(sono_ctx* c, const float* window, const double* tw_cos, const double* tw_sin) {
+  if (!c) return SONO_ERR_ARG;
+  if ((tw_cos == nullptr) != (tw_sin == nullptr)) return fail(c, SONO_ERR_ARG, "tw_cos and tw_sin must be given together");
+  HIP_TRY(c, hipSetDevice(c->device));
+  const uint32_t n = c->cfg.fft_n;
+  if (window) std::memcpy(c->h_window.data(), window, sizeof(float) * n);
+  if (tw_cos) {
+    std::memcpy(c->h_cos.data(), tw_cos, sizeof(double) * (n - 1));
+    std::memcpy(c->h_sin.data(), tw_sin, sizeof(double) * (n - 1));
+  }
+  return upload_tables(c);
+}
+
+int sono_geometry_of(const sono_ctx* c, uint64_t L, sono_geometry* out) {
+  if (!c || !out) return SONO_ERR_ARG;
+  return compute_geometry(c->cfg.fft_n, c->cfg.hop, c->cfg.frame_rule, c->bin_lo, c->bin_hi, L, out);
+}
+
+uint64_t sono_out_bytes(const sono_ctx* c, uint64_t L) {
+  sono_geometry g;
+  if (sono_geometry_of(c, L, &g) != SONO_OK) return 0;
+  switch (c->cfg.out_kind) {
+    case SONO_OUT_U8_INDEX: return g.frames * g.bins;
+    case SONO_OUT_RGBA8: return g.width * g.bins * 4;
+    default: return g.frames * g.bins * 4;
+  }
+}
+
+static uint64_t in_bytes(const sono_ctx* c, uint64_t L) { return L * (c->cfg.in_kind == SONO_IN_I16 ? 2 : 4); }
+
+static bool fast_eligible(const sono_ctx* c) {
+  return c->cfg.arith == SONO_ARITH_FAST_F32 && c->cfg.twiddle_mode == SONO_TW_ACCURATE;
+}
+
+int sono_stft_async(sono_ctx* c, const void* pcm, uint64_t L, void* out, uint64_t cap) {
+  if (!c) return SONO_ERR_ARG;
+  if (!out || (!pcm && L)) return fail(c, SONO_ERR_ARG, "NULL buffer");
+  sono_geometry g;
+  int rc = sono_geometry_of(c, L, &g);
+  if (rc != SONO_OK) return fail(c, rc, "bad geometry");
+  const uint64_t need = sono_out_bytes(c, L);
+  if (cap < need) return fail(c, SONO_ERR_CAPACITY, "output needs %llu bytes, capacity is %llu", (unsigned long long)need,
+                              (unsigned long long)cap);
+  HIP_TRY(c, hipSetDevice(c->device));
+  const uint32_t n = c->cfg.fft_n, H = n / 2;
+  const bool rgba = c->cfg.out_kind == SONO_OUT_RGBA8;
+  if (rgba && g.frames < g.width)  // L < N under the worker rule: a one-column, all-zero image (createImageData)
+    HIP_TRY(c, hipMemsetAsync(out, 0, need, c->stream));
+  if (g.frames == 0) return SONO_OK;
+
+  StftParams p{};
+  p.pcm = pcm;
+  p.n_samples = L;
+  p.n = n;
+  p.log2n = ilog2(n);
+  p.hop = c->cfg.hop;
+  p.width = g.width;
+  p.window = c->d_window;
+  p.twiddles = c->d_tw;
+  p.lut = c->have_lut ? c->d_lut : nullptr;
+  p.out = out;
+  p.scale_mode = c->cfg.scale_mode;
+  p.out_kind = c->cfg.out_kind;
+  p.in_kind = c->cfg.in_kind;
+  p.gain_db = c->cfg.gain_db;
+  p.range_db = c->cfg.range_db;
+  p.out_bins = g.bins;
+  p.out_bin0 = c->bin_lo;
+
+  auto launch = [&](const StftParams& q) -> int {
+    if ((q.frame0 + q.nframes - 1) * q.hop + q.n > q.n_samples) return fail(c, SONO_ERR_ARG, "frame range exceeds the signal");
+    int r = 1;
+    if (fast_eligible(c)) r = launch_stft_fast(q, c->stream);
+    if (r == 1) r = launch_stft_general(q, c->cfg.arith == SONO_ARITH_EXACT_F64, c->stream);
+    if (r != SONO_OK) return fail(c, r, "kernel launch failed: %s", hipGetErrorString(hipGetLastError()));
+    return SONO_OK;
+  };
+
+  // frames that have a column of their own
+  const uint64_t main_frames = g.frames < g.width ? g.frames : g.width;
+  p.frame0 = 0;
+  p.nframes = main_frames;
+  p.col0 = 0;
+  p.bin_lo = c->bin_lo;
+  p.bin_hi = c->bin_hi;
+  p.row_of_bin0 = (int32_t)c->bin_hi - 1;
+  rc = launch(p);
+  if (rc != SONO_OK) return rc;
+
+  if (g.frames > g.width) {
+    // worker quirk, spectrogramWorker.js:40,59,79: frame `width` is written at x == width, i.e. at
+    // column 0 one image row further down; its bin 0 falls off the end of the image.
+    if (rgba) {
+      StftParams q = p;
+      q.frame0 = g.width;
+      q.nframes = g.frames - g.width;  // always 1
+      q.col0 = 0;
+      q.bin_lo = c->bin_lo + 1;
+      q.bin_hi = (c->bin_hi + 1 <= H) ? c->bin_hi + 1 : H;
+      q.row_of_bin0 = (int32_t)c->bin_hi;  // one row down
+      if (q.bin_lo < q.bin_hi) {
+        rc = launch(q);
+        if (rc != SONO_OK) return rc;
+      }
+    } else {
+      // [frame][bin] outputs simply carry the extra frame as one more row
+      StftParams q = p;
+      q.frame0 = g.width;
+      q.nframes = g.frames - g.width;
+      q.col0 = g.width;
+      rc = launch(q);
+      if (rc != SONO_OK) return rc;
+    }
+  }
+  return SONO_OK;
+}
+
+int sono_wait(sono_ctx* c) {
+  if (!c) return SONO_ERR_ARG;
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return SONO_OK;
+}
+
+int sono_stft(sono_ctx* c, const void* pcm, uint64_t L, void* out, uint64_t cap, int mem) {
+  if (!c) return SONO_ERR_ARG;
+  if (mem == SONO_MEM_DEVICE) {
+    int rc = sono_stft_async(c, pcm, L, out, cap);
+    return rc != SONO_OK ? rc : sono_wait(c);
+  }
+  if (mem != SONO_MEM_HOST) return fail(c, SONO_ERR_ARG, "mem must be SONO_MEM_HOST or SONO_MEM_DEVICE");
+  if (!out || (!pcm && L)) return fail(c, SONO_ERR_ARG, "NULL buffer");
+  const uint64_t need = sono_out_bytes(c, L);
+  if (cap < need) return fail(c, SONO_ERR_CAPACITY, "output needs %llu bytes, capacity is %llu", (unsigned long long)need,
+                              (unsigned long long)cap);
+  HIP_TRY(c, hipSetDevice(c->device));
+  int rc = ensure(c, &c->d_in, &c->d_in_bytes, in_bytes(c, L));
+  if (rc != SONO_OK) return rc;
+  rc = ensure(c, &c->d_out, &c->d_out_bytes, need);
+  if (rc != SONO_OK) return rc;
+  if (L) HIP_TRY(c, hipMemcpyAsync(c->d_in, pcm, in_bytes(c, L), hipMemcpyHostToDevice, c->stream));
+  rc = sono_stft_async(c, c->d_in, L, c->d_out, c->d_out_bytes);
+  if (rc != SONO_OK) return rc;
+  if (need) HIP_TRY(c, hipMemcpyAsync(out, c->d_out, need, hipMemcpyDeviceToHost, c->stream));
+  return sono_wait(c);
+}
+
+int sono_resample(sono_ctx* c, const uint8_t* in, uint64_t F, uint32_t bins, uint64_t W, uint8_t* out, int mem) {
+  if (!c) return SONO_ERR_ARG;
+  if (!in || !out || bins == 0) return fail(c, SONO_ERR_ARG, "bad resample arguments");
+  HIP_TRY(c, hipSetDevice(c->device));
+  const uint8_t* din = in;
+  uint8_t* dout = out;
+  if (mem == SONO_MEM_HOST) {
+    int rc = ensure(c, &c->d_aux, &c->d_aux_bytes, F * bins);
+    if (rc != SONO_OK) return rc;
+    rc = ensure(c, &c->d_out, &c->d_out_bytes, W * bins);
+    if (rc != SONO_OK) return rc;
+    HIP_TRY(c, hipMemcpyAsync(c->d_aux, in, F * bins, hipMemcpyHostToDevice, c->stream));
+    din = (const uint8_t*)c->d_aux;
+    dout = (uint8_t*)c->d_out;
+  }
+  if (F == 0) HIP_TRY(c, hipMemsetAsync(dout, 0, W * bins, c->stream));
+  int rc = launch_resample(din, F, bins, W, dout, c->stream);
+  if (rc != SONO_OK) return fail(c, rc, "resample launch failed");
+  if (mem == SONO_MEM_HOST) HIP_TRY(c, hipMemcpyAsync(out, dout, W * bins, hipMemcpyDeviceToHost, c->stream));
+  return sono_wait(c);
+}
+
+int sono_colorize(sono_ctx* c, const uint8_t* frames, uint64_t width, uint32_t bins, uint32_t row0, uint32_t rows,
+                  uint8_t* rgba, int mem) {
+  if (!c) return SONO_ERR_ARG;
+  if (!frames || !rgba || bins == 0 || (uint64_t)row0 + rows > bins) return fail(c, SONO_ERR_ARG, "bad colorize arguments");
+  HIP_TRY(c, hipSetDevice(c->device));
+  const uint8_t* din = frames;
+  uint8_t* dout = rgba;
+  const uint64_t out_bytes = width * rows * 4;
+  if (mem == SONO_MEM_HOST) {
+    int rc = ensure(c, &c->d_aux, &c->d_aux_bytes, width * bins);
+    if (rc != SONO_OK) return rc;
+    rc = ensure(c, &c->d_out, &c->d_out_bytes, out_bytes);
+    if (rc != SONO_OK) return rc;
+    HIP_TRY(c, hipMemcpyAsync(c->d_aux, frames, width * bins, hipMemcpyHostToDevice, c->stream));
+    din = (const uint8_t*)c->d_aux;
+    dout = (uint8_t*)c->d_out;
+  }
+  int rc = launch_colorize(din, width, bins, row0, rows, c->have_lut ? c->d_lut : nullptr, dout, c->stream);
+  if (rc != SONO_OK) return fail(c, rc, "colorize launch failed");
+  if (mem == SONO_MEM_HOST && out_bytes) HIP_TRY(c, hipMemcpyAsync(rgba, dout, out_bytes, hipMemcpyDeviceToHost, c->stream));
+  return sono_wait(c);
+}
+
+int sono_frame_peaks(sono_ctx* c, const uint8_t* idx, uint64_t frames, uint32_t bins, int32_t* peak_bin, uint8_t* peak_idx,
+                     int mem) {
+  if (!c) return SONO_ERR_ARG;
+  if (!idx || !peak_bin || !peak_idx || bins == 0) return fail(c, SONO_ERR_ARG, "bad frame_peaks arguments");
+  HIP_TRY(c, hipSetDevice(c->device));
+  const uint8_t* din = idx;
+  int32_t* dbin = peak_bin;
+  uint8_t* dval = peak_idx;
+  if (mem == SONO_MEM_HOST) {
+    int rc = ensure(c, &c->d_aux, &c->d_aux_bytes, frames * bins);
+    if (rc != SONO_OK) return rc;
+    rc = ensure(c, &c->d_out, &c->d_out_bytes, frames * 8 + 64);
+    if (rc != SONO_OK) return rc;
+    HIP_TRY(c, hipMemcpyAsync(c->d_aux, idx, frames * bins, hipMemcpyHostToDevice, c->stream));
+    din = (const uint8_t*)c->d_aux;
+    dbin = (int32_t*)c->d_out;
+    dval = (uint8_t*)c->d_out + frames * 4;
+  }
+  int rc = launch_frame_peaks(din, frames, bins, dbin, dval, c->stream);
+  if (rc != SONO_OK) return fail(c, rc, "frame_peaks launch failed");
+  if (mem == SONO_MEM_HOST && frames) {
+    HIP_TRY(c, hipMemcpyAsync(peak_bin, dbin, frames * 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(peak_idx, dval, frames, hipMemcpyDeviceToHost, c->stream));
+  }
+  return sono_wait(c);
+}
+
+void* sono_device_malloc(sono_ctx* c, uint64_t bytes) {
+  if (!c) return nullptr;
+  void* p = nullptr;
+  if (hipSetDevice(c->device) != hipSuccess || hipMalloc(&p, bytes ? bytes : 1) != hipSuccess) {
+    fail(c, SONO_ERR_DEVICE, "hipMalloc(%llu) failed", (unsigned long long)bytes);
+    return nullptr;
+  }
+  return p;
+}
+
+int sono_device_free(sono_ctx* c, void* p) {
+  if (!c) return SONO_ERR_ARG;
+  HIP_TRY(c, hipSetDevice(c->device));
+  HIP_TRY(c, hipFree(p));
+  return SONO_OK;
+}
+
+int sono_copy_to_device(sono_ctx* c, void* dst, const void* src, uint64_t bytes) {
+  if (!c) return SONO_ERR_ARG;
+  HIP_TRY(c, hipSetDevice(c->device));
+  HIP_TRY(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
+  return sono_wait(c);
+}
+
+int sono_copy_to_host(sono_ctx* c, void* dst, const void* src, uint64_t bytes) {
+  if (!c) return SONO_ERR_ARG;
+  HIP_TRY(c, hipSetDevice(c->device));
+  HIP_TRY(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
+  return sono_wait(c);
+}
+
+int sono_timer_start(sono_ctx* c) {
+  if (!c) return SONO_ERR_ARG;
+  HIP_TRY(c, hipSetDevice(c->device));
+  HIP_TRY(c, hipEventRecord(c->ev_start, c->stream));
+  return SONO_OK;
+}
+
+double sono_timer_stop_ms(sono_ctx* c) {
+  if (!c) return -1.0;
+  if (hipEventRecord(c->ev_stop, c->stream) != hipSuccess || hipEventSynchronize(c->ev_stop) != hipSuccess) {
+    fail(c, SONO_ERR_DEVICE, "event record/synchronize failed");
+    return -1.0;
+  }
+  float ms = 0;
+  if (hipEventElapsedTime(&ms, c->ev_start, c->ev_stop) != hipSuccess) {
+    fail(c, SONO_ERR_DEVICE, "hipEventElapsedTime failed");
+    return -1.0;
+  }
+  return (double)ms;
+}
+
+}  // extern "C"

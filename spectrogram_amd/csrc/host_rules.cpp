@@ -1,0 +1,217 @@
+// Host-side rules of the spectrogram paths: geometry, overlap, crop window, colour LUTs, window
+// and twiddle tables.  Pure C++ (no GPU); compiled without FMA contraction because the tables
+// must be the IEEE double values the reference's JavaScript computes before its float32 store.
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "sonospec.h"
+#include "sono_internal.h"
+
+namespace sono {
+
+// ECMAScript Math.round: nearest integer, ties toward +infinity.
+static double ecma_round(double x) {
+  if (std::isnan(x) || std::isinf(x)) return x;
+  const double f = std::floor(x);
+  return (x - f >= 0.5) ? f + 1.0 : f;
+}
+
+// ECMAScript ToUint8Clamp: clamp to [0,255], ties to even.
+static uint8_t ecma_uint8_clamp(double v) {
+  if (std::isnan(v) || v <= 0) return 0;
+  if (v >= 255) return 255;
+  const double f = std::floor(v), d = v - f;
+  if (d < 0.5) return (uint8_t)f;
+  if (d > 0.5) return (uint8_t)(f + 1);
+  return (uint8_t)((((long)f) & 1) ? f + 1 : f);
+}
+
+bool is_pow2(uint32_t n) { return n != 0 && (n & (n - 1)) == 0; }
+
+uint32_t ilog2(uint32_t n) {
+  uint32_t l = 0;
+  while ((1u << l) < n) l++;
+  return l;
+}
+
+// spectrogram.esm.js:105-151 (plugin windows), spectrogramWorker.js:195-203 (worker Hann)
+int fill_window(uint32_t id, uint32_t n, double alpha, float* w) {
+  const double t = (double)n;
+  const double pi = 3.141592653589793;
+  const double e = 2.718281828459045;
+  switch (id) {
+    case SONO_WIN_BARTLETT:
+      for (uint32_t i = 0; i < n; i++) w[i] = (float)(2 / (t - 1) * ((t - 1) / 2 - std::fabs(i - (t - 1) / 2)));
+      return SONO_OK;
+    case SONO_WIN_BARTLETT_HANN:
+      for (uint32_t i = 0; i < n; i++)
+        w[i] = (float)(.62 - .48 * std::fabs(i / (t - 1) - .5) - .38 * std::cos(2 * pi * i / (t - 1)));
+      return SONO_OK;
+    case SONO_WIN_BLACKMAN: {
+      const double r = (alpha > 0) ? alpha : .16;
+      for (uint32_t i = 0; i < n; i++)
+        w[i] = (float)((1 - r) / 2 - .5 * std::cos(2 * pi * i / (t - 1)) + r / 2 * std::cos(4 * pi * i / (t - 1)));
+      return SONO_OK;
+    }
+    case SONO_WIN_COSINE:
+      for (uint32_t i = 0; i < n; i++) w[i] = (float)std::cos(pi * i / (t - 1) - pi / 2);
+      return SONO_OK;
+    case SONO_WIN_GAUSS: {
+      const double r = (alpha > 0) ? alpha : .25;
+      for (uint32_t i = 0; i < n; i++)
+        w[i] = (float)std::pow(e, -.5 * std::pow((i - (t - 1) / 2) / (r * (t - 1) / 2), 2));
+      return SONO_OK;
+    }
+    case SONO_WIN_HAMMING:
+      for (uint32_t i = 0; i < n; i++) w[i] = (float)(.54 - .46 * std::cos(2 * pi * i / (t - 1)));
+      return SONO_OK;
+    case SONO_WIN_HANN:
+      for (uint32_t i = 0; i < n; i++) w[i] = (float)(.5 * (1 - std::cos(2 * pi * i / (t - 1))));
+      return SONO_OK;
+    case SONO_WIN_LANCZOZ:
+      for (uint32_t i = 0; i < n; i++)
+        w[i] = (float)(std::sin(pi * (2 * i / (t - 1) - 1)) / (pi * (2 * i / (t - 1) - 1)));
+      return SONO_OK;
+    case SONO_WIN_RECTANGULAR:
+      for (uint32_t i = 0; i < n; i++) w[i] = 1.0f;
+      return SONO_OK;
+    case SONO_WIN_TRIANGULAR:
+      for (uint32_t i = 0; i < n; i++) w[i] = (float)(2 / t * (t / 2 - std::fabs(i - (t - 1) / 2)));
+      return SONO_OK;
+    case SONO_WIN_WORKER_HANN: {
+      const double invN = 1.0 / (t - 1), twoPI = 2 * pi;
+      for (uint32_t i = 0; i < n; i++) w[i] = (float)(0.5 * (1 - std::cos(twoPI * i * invN)));
+      return SONO_OK;
+    }
+    default:
+      return SONO_ERR_WINDOW;
+  }
+}
+
+// Flat stage layout: the stage whose butterflies span half size T uses entries [T-1, 2T-1).
+int fill_twiddles(uint32_t mode, uint32_t n, double* c, double* s) {
+  const double pi = 3.141592653589793;
+  if (mode == SONO_TW_ACCURATE) {  // spectrogramWorker.js:110-125
+    for (uint32_t n1 = 1; n1 < n; n1 <<= 1) {
+      const uint32_t n2 = n1 << 1;
+      for (uint32_t j = 0; j < n1; j++) {
+        const double angle = -2 * pi * j / n2;
+        c[n1 - 1 + j] = std::cos(angle);
+        s[n1 - 1 + j] = std::sin(angle);
+      }
+    }
+    return SONO_OK;
+  }
+  if (mode == SONO_TW_PLUGIN_RECURRENCE) {  // spectrogram.esm.js:158-160,176-190
+    for (uint32_t T = 1; T < n; T <<= 1) {
+      const double d = (double)(float)std::cos(-pi / T);
+      const double w = (double)(float)std::sin(-pi / T);
+      double g = 1, b = 0;
+      for (uint32_t z = 0; z < T; z++) {
+        c[T - 1 + z] = g;
+        s[T - 1 + z] = b;
+        const double v = g;
+        g = v * d - b * w;
+        b = v * w + b * d;
+      }
+    }
+    return SONO_OK;
+  }
+  return SONO_ERR_ARG;
+}
+
+int compute_geometry(uint32_t n, uint32_t hop, uint32_t rule, uint32_t bin_lo, uint32_t bin_hi, uint64_t L,
+                     sono_geometry* g) {
+  if (!is_pow2(n) || n < 2) return SONO_ERR_FFT_SIZE;
+  if (hop == 0) return SONO_ERR_ARG;
+  const uint32_t half = n / 2;
+  if (bin_hi == 0) bin_hi = half;
+  if (bin_hi > half || bin_lo >= bin_hi) return SONO_ERR_ARG;
+  g->bins = bin_hi - bin_lo;
+  g->hop = hop;
+  const uint64_t cols = (L > n) ? (L - n + hop - 1) / hop : 0;  // ceil((L-N)/hop), 0 when L <= N
+  if (rule == SONO_FRAMES_PLUGIN_STRICT) {  // spectrogram.esm.js:526
+    g->frames = cols;
+    g->width = cols;
+  } else if (rule == SONO_FRAMES_WORKER_COMPAT) {  // spectrogramWorker.js:40,59
+    g->frames = (L >= n) ? (L - n) / hop + 1 : 0;
+    g->width = cols > 1 ? cols : 1;
+  } else {
+    return SONO_ERR_ARG;
+  }
+  return SONO_OK;
+}
+
+}  // namespace sono
+
+using namespace sono;
+
+extern "C" {
+
+int sono_abi_version(void) { return SONOSPEC_ABI_VERSION; }
+
+uint32_t sono_worker_hop(uint32_t n, double pct) {  // spectrogramWorker.js:39
+  const double h = std::floor((double)n * (1 - pct / 100));
+  return h > 1 ? (uint32_t)h : 1u;
+}
+
+uint32_t sono_plugin_noverlap(uint32_t n, uint32_t noverlap, uint64_t L, uint32_t canvas_width) {
+  if (noverlap > 0) return noverlap;  // spectrogram.esm.js:502-506 (0 / null / undefined are all "auto")
+  if (canvas_width == 0) return 0;
+  const double e = (double)L / (double)canvas_width;
+  const double o = ecma_round((double)n - e);
+  return o > 0 ? (uint32_t)o : 0u;
+}
+
+uint32_t sono_overlap_from_percent(uint32_t n, double pct) {  // wsManager.js:87-89
+  const double v = std::floor((double)n * (pct / 100));
+  return v > 0 ? (uint32_t)v : 0u;
+}
+
+int sono_geometry_for(uint32_t n, uint32_t hop, uint32_t rule, uint32_t bin_lo, uint32_t bin_hi, uint64_t L,
+                      sono_geometry* out) {
+  if (!out) return SONO_ERR_ARG;
+  return compute_geometry(n, hop, rule, bin_lo, bin_hi, L, out);
+}
+
+int sono_plugin_crop(uint32_t bins, double sample_rate, double fmin, double fmax, int64_t* sy, int64_t* sh) {
+  if (!sy || !sh || !(sample_rate > 0)) return SONO_ERR_ARG;
+  const double nyq = sample_rate / 2;  // spectrogram.esm.js:353
+  if (fmax == 0) fmax = nyq;           // :496
+  const double u = fmin / nyq, f = fmax / nyq;
+  const double p = f < 1 ? f : 1;      // :377-379 with hzToScale == identity (:464)
+  *sy = (int64_t)ecma_round((double)bins * (1 - p));
+  *sh = (int64_t)ecma_round((double)bins * (p - u));
+  return SONO_OK;
+}
+
+int sono_plugin_lut(const double* cm, uint8_t* lut) {  // spectrogram.esm.js:262-271
+  if (!cm || !lut) return SONO_ERR_ARG;
+  for (int i = 0; i < 1024; i++) lut[i] = ecma_uint8_clamp(ecma_round(255 * cm[i]));
+  return SONO_OK;
+}
+
+int sono_worker_lut(const double* cm, uint8_t* lut) {  // spectrogramWorker.js:128-143
+  if (!cm || !lut) return SONO_ERR_ARG;
+  for (int i = 0; i < 256; i++)
+    for (int ch = 0; ch < 4; ch++) {
+      double v = cm[i * 4 + ch];
+      if (std::isnan(v)) v = (ch < 3) ? 0.0 : 1.0;
+      lut[i * 4 + ch] = ecma_uint8_clamp(ecma_round(255 * v));
+    }
+  return SONO_OK;
+}
+
+int sono_window_table(uint32_t id, uint32_t n, double alpha, float* out) {
+  if (!out || n < 2) return SONO_ERR_ARG;
+  return fill_window(id, n, alpha, out);
+}
+
+int sono_twiddle_table(uint32_t mode, uint32_t n, double* c, double* s) {
+  if (!c || !s) return SONO_ERR_ARG;
+  if (!is_pow2(n)) return SONO_ERR_FFT_SIZE;
+  return fill_twiddles(mode, n, c, s);
+}
+
+}  // extern "C"

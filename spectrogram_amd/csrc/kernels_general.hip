@@ -1,0 +1,190 @@
+// General STFT kernel: the reference's radix-2 decimation-in-time dataflow with per-stage
+// twiddle tables, for any power-of-two size, in two arithmetics.
+//
+//   float  : float32 butterflies (dB within 0.01 dB of the JavaScript, indices within 1 LSB)
+//   double : double butterflies, float32 rounding at every store, no FMA contraction -- the exact
+//            operation sequence of spectrogramWorker.js:233-252 and spectrogram.esm.js:175-193
+//            (JavaScript doubles over Float32Array storage), so magnitudes are bit-identical.
+//
+// Because the twiddles come from a table, the same kernel serves the worker's accurate factors
+// and the plugin's recurrence factors (which are not exact roots of unity, so no algebraic
+// shortcut between stages is allowed).
+//
+// One 256-thread workgroup transforms FT consecutive frames, one after the other, in LDS.  For
+// [frame][bin] outputs each frame's bins are stored directly; for the RGBA image the colour
+// indices of the FT frames are kept in an LDS tile and written as runs of FT pixels per image
+// row, so that global stores are contiguous instead of one pixel per row.
+//
+// Compile with -ffp-contract=off.
+#include <hip/hip_runtime.h>
+
+#include "sono_device.h"
+#include "sono_internal.h"
+
+namespace sono {
+
+constexpr int kThreads = 256;
+
+template <typename T>
+struct Tw2;
+template <>
+struct Tw2<float> {
+  using type = float2;
+};
+template <>
+struct Tw2<double> {
+  using type = double2;
+};
+
+template <typename In>
+__device__ __forceinline__ float load_sample(const In* x, uint64_t i);
+template <>
+__device__ __forceinline__ float load_sample<float>(const float* x, uint64_t i) {
+  return x[i];
+}
+template <>
+__device__ __forceinline__ float load_sample<int16_t>(const int16_t* x, uint64_t i) {
+  return (float)x[i] * (1.0f / 32768.0f);
+}
+
+template <typename A /* float | double */, typename In>
+__global__ __launch_bounds__(kThreads) void stft_general_kernel(StftParams p, FastScale fs, uint32_t frames_per_block,
+                                                               uint32_t tile_stride) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* re = reinterpret_cast<float*>(smem);
+  float* im = re + p.n;
+  unsigned char* tile = reinterpret_cast<unsigned char*>(im + p.n);  // [frames_per_block][tile_stride]
+
+  using TW = typename Tw2<A>::type;
+  const TW* __restrict__ tw = reinterpret_cast<const TW*>(p.twiddles);
+  const In* __restrict__ x = reinterpret_cast<const In*>(p.pcm);
+  const uint32_t n = p.n, half = n >> 1;
+  const uint32_t tid = threadIdx.x;
+  const uint64_t first = (uint64_t)blockIdx.x * frames_per_block;
+  const uint32_t count = (uint32_t)min((uint64_t)frames_per_block, p.nframes - first);
+  const uint32_t nb = p.bin_hi - p.bin_lo;
+  const double two_over_n = 2.0 / (double)n;
+
+  for (uint32_t fl = 0; fl < count; ++fl) {
+    const uint64_t frame = p.frame0 + first + fl;
+    const uint64_t a = frame * p.hop;
+    // window, spectrogramWorker.js:61-64 / spectrogram.esm.js:172-174: float32(x*w) at the
+    // bit-reversed position (a float32 product equals the float32 rounding of the double product)
+    for (uint32_t j = tid; j < n; j += kThreads) {
+      const uint32_t k = __brev(j) >> (32 - p.log2n);
+      re[k] = load_sample<In>(x, a + j) * p.window[j];
+      im[k] = 0.0f;
+    }
+    for (uint32_t T = 1; T < n; T <<= 1) {
+      __syncthreads();
+      for (uint32_t b = tid; b < half; b += kThreads) {
+        const uint32_t z = b & (T - 1);
+        const uint32_t k = ((b - z) << 1) + z;
+        const uint32_t M = k + T;
+        const TW w = tw[T - 1 + z];
+        const A g = w.x, s = w.y;
+        const A oM = re[M], lM = im[M], ok = re[k], lk = im[k];
+        const A m = g * oM - s * lM;
+        const A y = g * lM + s * oM;
+        re[M] = (float)(ok - m);
+        im[M] = (float)(lk - y);
+        re[k] = (float)(ok + m);
+        im[k] = (float)(lk + y);
+      }
+    }
+    __syncthreads();
+    for (uint32_t y = p.bin_lo + tid; y < p.bin_hi; y += kThreads) {
+      const float r = re[y], i = im[y];
+      if (p.out_kind == SONO_OUT_U8_INDEX || p.out_kind == SONO_OUT_RGBA8) {
+        uint32_t idx;
+        if constexpr (sizeof(A) == 8) {
+          idx = (p.scale_mode == SONO_SCALE_WORKER_LOG5)
+                    ? worker_index_exact(r, i)
+                    : plugin_index_exact(plugin_mag_exact(r, i, two_over_n), p.gain_db, p.range_db);
+        } else {
+          idx = fast_index(r * r + i * i, fs);
+        }
+        if (p.out_kind == SONO_OUT_U8_INDEX)
+          reinterpret_cast<uint8_t*>(p.out)[(p.col0 + first + fl) * p.out_bins + (y - p.out_bin0)] = (uint8_t)idx;
+        else
+          tile[fl * tile_stride + (y - p.bin_lo)] = (unsigned char)idx;
+      } else {
+        float v;
+        if constexpr (sizeof(A) == 8) {
+          const double e = r, s = i;
+          const double mag = sqrt(e * e + s * s);
+          const float m = (p.scale_mode == SONO_SCALE_WORKER_LOG5) ? (float)mag : (float)(two_over_n * mag);
+          if (p.out_kind == SONO_OUT_F32_MAG) {
+            v = m;
+          } else {
+            const double sv = ((double)m > 1e-12) ? (double)m : 1e-12;
+            v = (float)(20 * log10(sv));
+          }
+        } else {
+          const float msq = r * r + i * i;
+          if (p.out_kind == SONO_OUT_F32_MAG)
+            v = sqrtf(msq) * ((p.scale_mode == SONO_SCALE_WORKER_LOG5) ? 1.0f : (float)two_over_n);
+          else
+            v = fast_db(msq, fs);
+        }
+        reinterpret_cast<float*>(p.out)[(p.col0 + first + fl) * p.out_bins + (y - p.out_bin0)] = v;
+      }
+    }
+    __syncthreads();  // re/im are rewritten by the next frame
+  }
+
+  if (p.out_kind == SONO_OUT_RGBA8) {
+    // image row of bin y is row_of_bin0 - y; columns first.. are contiguous in memory
+    uint32_t* img = reinterpret_cast<uint32_t*>(p.out);
+    const uint32_t total = nb * count;
+    for (uint32_t i = tid; i < total; i += kThreads) {
+      const uint32_t by = i / count, c = i - by * count;
+      const uint32_t y = p.bin_lo + by;
+      const uint32_t idx = tile[c * tile_stride + by];
+      const uint32_t px = p.lut ? p.lut[idx] : (idx | (idx << 8) | (idx << 16) | 0xff000000u);
+      const int64_t row = (int64_t)p.row_of_bin0 - (int64_t)y;
+      img[(uint64_t)row * p.width + p.col0 + first + c] = px;
+    }
+  }
+}
+
+int launch_stft_general(const StftParams& p, bool exact_f64, void* stream_v) {
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_v);
+  if (p.nframes == 0) return SONO_OK;
+  const uint32_t nb = p.bin_hi - p.bin_lo;
+  // RGBA: keep FT frames of indices in LDS; the row stride in dwords is odd so that the
+  // column-major read-out does not hit one bank.
+  uint32_t ft = 1, stride = 0;
+  size_t lds = (size_t)p.n * 2 * sizeof(float);
+  if (p.out_kind == SONO_OUT_RGBA8) {
+    stride = ((nb + 3) / 4) * 4;
+    if (((stride / 4) & 1) == 0) stride += 4;
+    const size_t budget = 64 * 1024;
+    ft = (uint32_t)(budget / stride);
+    if (ft > 64) ft = 64;
+    if (ft < 1) ft = 1;
+    lds += (size_t)ft * stride;
+  } else {
+    ft = 8;
+  }
+  const uint64_t blocks = (p.nframes + ft - 1) / ft;
+  if (blocks > 0x7fffffffull) return SONO_ERR_ARG;
+  const FastScale fs = make_fast_scale(p.scale_mode, p.n, p.gain_db, p.range_db);
+  dim3 grid((uint32_t)blocks), block(kThreads);
+#define SONO_LAUNCH(A, In)                                                                                  \
+  do {                                                                                                      \
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&stft_general_kernel<A, In>),                     \
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)            \
+      return SONO_ERR_DEVICE;                                                                               \
+    hipLaunchKernelGGL((stft_general_kernel<A, In>), grid, block, lds, stream, p, fs, ft, stride);          \
+  } while (0)
+  if (exact_f64) {
+    if (p.in_kind == SONO_IN_I16) SONO_LAUNCH(double, int16_t); else SONO_LAUNCH(double, float);
+  } else {
+    if (p.in_kind == SONO_IN_I16) SONO_LAUNCH(float, int16_t); else SONO_LAUNCH(float, float);
+  }
+#undef SONO_LAUNCH
+  return hipGetLastError() == hipSuccess ? SONO_OK : SONO_ERR_DEVICE;
+}
+
+}  // namespace sono

@@ -1,0 +1,136 @@
+// Post-processing kernels of the plugin path: time resample, colour LUT + flip + row window,
+// and the per-frame peak reduction.  Compile with -ffp-contract=off (resample accumulates in
+// double in the reference's order).
+#include <hip/hip_runtime.h>
+
+#include "sono_internal.h"
+
+namespace sono {
+
+// ------------------------------------------------------------------------------------------
+// resample, spectrogram.esm.js:595-640.  One workgroup per output column a; threads over bins.
+// The reference tests every input frame n against the column; frames far from the column have
+// no overlap, so only [n0, n1) (two frames of margin) are tested, with the reference's own
+// double expressions deciding membership and weight, in ascending n like its contrib list.
+__global__ __launch_bounds__(256) void resample_kernel(const uint8_t* __restrict__ in, uint64_t F, uint32_t bins,
+                                                      uint64_t W, double invIn, double invOut,
+                                                      uint8_t* __restrict__ out) {
+  const uint64_t a = blockIdx.x;
+  const double o = (double)a * invOut, l = o + invOut;
+  double lo_f = floor((double)a * (double)F / (double)W) - 2;
+  double hi_f = ceil((double)(a + 1) * (double)F / (double)W) + 2;
+  const uint64_t n0 = lo_f < 0 ? 0 : (uint64_t)lo_f;
+  const uint64_t n1 = hi_f > (double)F ? F : (uint64_t)hi_f;
+  for (uint32_t u = threadIdx.x; u < bins; u += blockDim.x) {
+    double accum = 0;
+    bool any = false;
+    for (uint64_t n = n0; n < n1; ++n) {
+      const double s = (double)n * invIn, h = s + invIn;
+      const double mn = h < l ? h : l, mx = s > o ? s : o;
+      const double c = mn - mx;
+      if (!(c > 0)) continue;
+      const double weight = c / invOut;
+      accum += weight * (double)in[n * bins + u];
+      any = true;
+    }
+    uint32_t v = 0;
+    if (any && fabs(accum) < 1e15) v = (uint32_t)((long long)trunc(accum) & 255);  // Uint8Array store
+    out[a * bins + u] = (uint8_t)v;
+  }
+}
+
+int launch_resample(const uint8_t* in, uint64_t F, uint32_t bins, uint64_t W, uint8_t* out, void* stream_v) {
+  if (W == 0 || F == 0) return SONO_OK;
+  if (W > 0x7fffffffull) return SONO_ERR_ARG;
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_v);
+  hipLaunchKernelGGL(resample_kernel, dim3((uint32_t)W), dim3(256), 0, stream, in, F, bins, W, 1.0 / (double)F,
+                     1.0 / (double)W, out);
+  return hipGetLastError() == hipSuccess ? SONO_OK : SONO_ERR_DEVICE;
+}
+
+// ------------------------------------------------------------------------------------------
+// LUT + vertical flip (+ row window), spectrogram.esm.js:366-380.  frames is [width][bins];
+// image row r holds bin bins-1-r.  A 64x64 tile goes through LDS so that both the byte reads
+// (along bins) and the pixel writes (along columns) are contiguous.
+constexpr int kTile = 64;
+
+__global__ __launch_bounds__(256) void colorize_kernel(const uint8_t* __restrict__ frames, uint64_t width, uint32_t bins,
+                                                      uint32_t row0, uint32_t rows, const uint32_t* __restrict__ lut,
+                                                      uint32_t* __restrict__ rgba) {
+  __shared__ uint8_t tile[kTile][kTile + 4];
+  const uint64_t t0 = (uint64_t)blockIdx.x * kTile;  // first column of the tile
+  const uint32_t r0 = blockIdx.y * kTile;            // first output row of the tile (relative to row0)
+  const uint32_t tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  // read: thread tx walks bins (contiguous bytes of one frame)
+  for (uint32_t c = ty; c < kTile; c += 4) {
+    const uint64_t t = t0 + c;
+    const uint32_t r = r0 + tx;  // output row (relative)
+    uint8_t v = 0;
+    if (t < width && r < rows) {
+      const uint32_t e = bins - 1 - (row0 + r);
+      v = frames[t * bins + e];
+    }
+    tile[c][tx] = v;
+  }
+  __syncthreads();
+  // write: thread tx walks columns (contiguous pixels of one image row)
+  for (uint32_t rr = ty; rr < kTile; rr += 4) {
+    const uint32_t r = r0 + rr;
+    const uint64_t t = t0 + tx;
+    if (t < width && r < rows) {
+      const uint32_t idx = tile[tx][rr];
+      rgba[(uint64_t)r * width + t] = lut ? lut[idx] : (idx | (idx << 8) | (idx << 16) | 0xff000000u);
+    }
+  }
+}
+
+int launch_colorize(const uint8_t* frames, uint64_t width, uint32_t bins, uint32_t row0, uint32_t rows,
+                    const uint32_t* lut, uint8_t* rgba, void* stream_v) {
+  if (width == 0 || rows == 0) return SONO_OK;
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_v);
+  const uint64_t gx = (width + kTile - 1) / kTile;
+  const uint32_t gy = (rows + kTile - 1) / kTile;
+  if (gx > 0x7fffffffull || gy > 65535u) return SONO_ERR_ARG;
+  hipLaunchKernelGGL(colorize_kernel, dim3((uint32_t)gx, gy), dim3(256), 0, stream, frames, width, bins, row0, rows,
+                     lut, reinterpret_cast<uint32_t*>(rgba));
+  return hipGetLastError() == hipSuccess ? SONO_OK : SONO_ERR_DEVICE;
+}
+
+// ------------------------------------------------------------------------------------------
+// Per-frame peak: first bin holding the maximum index (strict > in ascending bin order, the
+// rule of spectrogram.esm.js:196).  One wavefront per frame.
+__global__ __launch_bounds__(256) void frame_peaks_kernel(const uint8_t* __restrict__ idx, uint64_t frames, uint32_t bins,
+                                                         int32_t* __restrict__ peak_bin, uint8_t* __restrict__ peak_idx) {
+  const uint32_t lane = threadIdx.x & 63;
+  const uint64_t f = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (f >= frames) return;
+  const uint8_t* row = idx + f * bins;
+  // key = value << 16 | (0xffff - bin): the largest key is the largest value at the smallest bin
+  uint32_t best = 0;
+  for (uint32_t k = lane; k < bins; k += 64) {
+    const uint32_t key = ((uint32_t)row[k] << 16) | (0xffffu - k);
+    best = key > best ? key : best;
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    const uint32_t other = __shfl_xor(best, off);
+    best = other > best ? other : best;
+  }
+  if (lane == 0) {
+    peak_bin[f] = (int32_t)(0xffffu - (best & 0xffffu));
+    peak_idx[f] = (uint8_t)(best >> 16);
+  }
+}
+
+int launch_frame_peaks(const uint8_t* idx, uint64_t frames, uint32_t bins, int32_t* peak_bin, uint8_t* peak_idx,
+                       void* stream_v) {
+  if (frames == 0) return SONO_OK;
+  if (bins == 0 || bins > 0xffffu) return SONO_ERR_ARG;
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_v);
+  const uint64_t blocks = (frames + 3) / 4;
+  if (blocks > 0x7fffffffull) return SONO_ERR_ARG;
+  hipLaunchKernelGGL(frame_peaks_kernel, dim3((uint32_t)blocks), dim3(256), 0, stream, idx, frames, bins, peak_bin,
+                     peak_idx);
+  return hipGetLastError() == hipSuccess ? SONO_OK : SONO_ERR_DEVICE;
+}
+
+}  // namespace sono

@@ -1,0 +1,88 @@
+// Device-side helpers shared by the STFT kernels: the two quantisers in both arithmetics.
+#ifndef SONO_DEVICE_H
+#define SONO_DEVICE_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "sonospec.h"
+
+namespace sono {
+
+// ---------------------------------------------------------------- exact (double) quantisers
+// Worker pixel value, spectrogramWorker.js:71-78.
+__device__ __forceinline__ uint32_t worker_index_exact(float re, float im) {
+  const double magSq = (double)re * (double)re + (double)im * (double)im;
+  const double mag = sqrt(magSq);
+  double val = (mag > 1e-12) ? log10(mag) / 5 : -2.4;
+  val = val < 0 ? 0 : (val > 1 ? 1 : val);
+  return (uint32_t)floor(val * 255);
+}
+
+// Plugin magnitude, spectrogram.esm.js:195-198: float32 of (2/N)*sqrt(re^2+im^2).
+__device__ __forceinline__ float plugin_mag_exact(float re, float im, double two_over_n) {
+  const double e = re, s = im;
+  return (float)(two_over_n * sqrt(e * e + s * s));
+}
+
+// Plugin colour index, spectrogram.esm.js:531-535 (Uint8Array store = truncate, modulo 256).
+__device__ __forceinline__ uint32_t plugin_index_exact(float m, double gain, double range) {
+  const double s = ((double)m > 1e-12) ? (double)m : 1e-12;
+  const double r = 20 * log10(s);
+  if (r < -gain - range) return 0;
+  if (r > -gain) return 255;
+  const double v = (r + gain) / range * 255 + 256;
+  if (!(fabs(v) < 1e15)) return 0;  // NaN / infinity store 0
+  return (uint32_t)((long long)trunc(v) & 255);
+}
+
+// ---------------------------------------------------------------- fast (float32) quantisers
+// Both work from |X|^2 so no square root is needed: log10|X| = 0.5*log10(2)*log2(|X|^2).
+struct FastScale {
+  float a, b;     // t = log2(|X|^2) * a + b
+  float t_floor;  // plugin: t at the 1e-12 magnitude floor (r = -240 dB)
+  float db_off;   // dB = 10*log10(2) * log2(|X|^2) + db_off
+  uint32_t mode;
+};
+
+__host__ __device__ inline FastScale make_fast_scale(uint32_t mode, uint32_t n, double gain, double range) {
+  FastScale s;
+  s.mode = mode;
+  const double l10_2 = 0.30102999566398119521;
+  if (mode == SONO_SCALE_WORKER_LOG5) {
+    s.a = (float)(255.0 * 0.5 * l10_2 / 5.0);  // 255 * log10|X| / 5
+    s.b = 0.0f;
+    s.t_floor = 0.0f;
+    s.db_off = 0.0f;
+  } else {
+    // r = 20*log10(2/N*|X|) = 10*log10(2)*(log2|X|^2 + 2*log2(2/N));  t = (r+gain)/range*255 + 256
+    const double lg = 2.0 * (1.0 - log2((double)n));
+    s.a = (float)(10.0 * l10_2 * 255.0 / range);
+    s.b = (float)((10.0 * l10_2 * lg + gain) * 255.0 / range + 256.0);
+    s.t_floor = (float)((-240.0 + gain) * 255.0 / range + 256.0);
+    s.db_off = (float)(10.0 * l10_2 * lg);
+  }
+  return s;
+}
+
+__device__ __forceinline__ uint32_t fast_index(float mag_sq, const FastScale& s) {
+  const float lg = __log2f(mag_sq);
+  if (s.mode == SONO_SCALE_WORKER_LOG5) {
+    float t = lg * s.a;
+    t = fminf(fmaxf(t, 0.0f), 255.0f);  // NaN -> 0 like the reference's failed comparison
+    return (uint32_t)t;
+  }
+  const float t = fmaxf(lg * s.a + s.b, s.t_floor);  // NaN takes the floor, as `n > 1e-12` fails for NaN
+  if (!(t >= 1.0f)) return 0;    // r < -gain-range
+  if (t > 256.0f) return 255;    // r > -gain
+  return ((uint32_t)t) & 255u;   // t == 256 wraps to 0 like the Uint8Array store
+}
+
+__device__ __forceinline__ float fast_db(float mag_sq, const FastScale& s) {
+  // 20*log10(max(m, 1e-12))
+  const float db = 3.0102999566f * __log2f(mag_sq) + s.db_off;
+  return fmaxf(db, -240.0f);
+}
+
+}  // namespace sono
+#endif

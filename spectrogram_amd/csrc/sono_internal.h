@@ -1,0 +1,52 @@
+// Internal declarations shared by the translation units of libsonospec.so.
+#ifndef SONO_INTERNAL_H
+#define SONO_INTERNAL_H
+
+#include <stdint.h>
+
+#include "sonospec.h"
+
+namespace sono {
+
+bool is_pow2(uint32_t n);
+uint32_t ilog2(uint32_t n);
+int fill_window(uint32_t id, uint32_t n, double alpha, float* w);
+int fill_twiddles(uint32_t mode, uint32_t n, double* c, double* s);
+int compute_geometry(uint32_t n, uint32_t hop, uint32_t rule, uint32_t bin_lo, uint32_t bin_hi, uint64_t L,
+                     sono_geometry* g);
+
+// One launch of an STFT kernel: frames [frame0, frame0 + nframes) of one signal.
+struct StftParams {
+  const void* pcm;        // device: float32 or int16 samples
+  uint64_t n_samples;
+  uint32_t n, log2n, hop;
+  uint64_t frame0;        // first frame of this launch
+  uint64_t nframes;       // number of frames in this launch
+  uint64_t col0;          // RGBA: image column of frame0
+  uint64_t width;         // RGBA: image width in pixels
+  uint32_t bin_lo, bin_hi;  // bins written: [bin_lo, bin_hi)
+  int32_t row_of_bin0;    // RGBA: image row of bin y is row_of_bin0 - y
+  uint32_t out_bins;      // [frame][bin] outputs: row length
+  uint32_t out_bin0;      // [frame][bin] outputs: bin stored at column 0
+  const float* window;    // device, n floats
+  const void* twiddles;   // device, n-1 float2 (fast) or double2 (exact), flat stage layout
+  const uint32_t* lut;    // device, 256 packed RGBA (little endian r | g<<8 | b<<16 | a<<24), or nullptr = grey
+  void* out;              // device
+  uint32_t scale_mode, out_kind, in_kind;
+  double gain_db, range_db;
+};
+
+// kernels_general.hip: table-driven radix-2 dataflow, any power-of-two size, both arithmetics.
+int launch_stft_general(const StftParams& p, bool exact_f64, void* hip_stream);
+// kernels_fast.hip: float32 kernels with accurate twiddles (returns 1 if this size/mode has no fast kernel).
+int launch_stft_fast(const StftParams& p, void* hip_stream);
+// kernels_post.hip
+int launch_resample(const uint8_t* in, uint64_t in_frames, uint32_t bins, uint64_t out_width, uint8_t* out,
+                    void* hip_stream);
+int launch_colorize(const uint8_t* frames, uint64_t width, uint32_t bins, uint32_t row0, uint32_t rows,
+                    const uint32_t* lut, uint8_t* rgba, void* hip_stream);
+int launch_frame_peaks(const uint8_t* idx, uint64_t frames, uint32_t bins, int32_t* peak_bin, uint8_t* peak_idx,
+                       void* hip_stream);
+
+}  // namespace sono
+#endif

@@ -1,0 +1,166 @@
+"""CPU-only checks of libsonospec.so's host side: the library loads without a GPU, exports every
+symbol of include/sonospec.h, and its host rules (geometry, overlap, crop, LUTs, tables) agree
+with the reference outputs in tests/golden/."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, golden_store
+from spectrogram_amd import _ffi as F
+from spectrogram_amd import engine as E
+from spectrogram_amd.plugin import Spectrogram, createSpectrogramPlugin, noverlap_from_percent
+
+G = golden_store()
+WINDOWS = ["bartlett", "bartlettHann", "blackman", "cosine", "gauss", "hamming", "hann", "lanczoz",
+           "rectangular", "triangular"]
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "sonospec.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(sono_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 30
+    lib = F.lib()
+    for name in sorted(declared):
+        assert hasattr(lib, name), name
+    assert declared == set(F.SYMBOLS), declared ^ set(F.SYMBOLS)
+    assert lib.sono_abi_version() == 1
+    assert lib.sono_device_count() >= 0
+
+
+def test_config_struct_layout():
+    import ctypes as C
+    assert C.sizeof(F.SonoConfig) == 88 and F.SonoConfig.alpha.offset == 48
+    assert C.sizeof(F.SonoGeometry) == 24
+
+
+def test_windows_match_reference():
+    for case in G.cases("plugin_tables"):
+        n = case["N"]
+        ref = G.load(case["window_values"], np.float32).reshape(len(WINDOWS), n)
+        for i, w in enumerate(WINDOWS):
+            got = E.window_table(F.WINDOW_IDS[w], n)
+            assert np.array_equal(got.view(np.uint32), ref[i].view(np.uint32)), (w, n)
+    for case in G.cases("worker_tables"):
+        got = E.window_table(F.WIN_WORKER_HANN, case["N"])
+        assert np.array_equal(got.view(np.uint32), G.load(case["hann"], np.float32).view(np.uint32))
+    (case,) = G.cases("plugin_alpha_windows")
+    ref = G.load(case["window_values"], np.float32).reshape(len(case["alphas"]), 2, case["N"])
+    for i, al in enumerate(case["alphas"]):
+        assert np.array_equal(E.window_table(F.WINDOW_IDS["blackman"], case["N"], al), ref[i, 0])
+        assert np.array_equal(E.window_table(F.WINDOW_IDS["gauss"], case["N"], al), ref[i, 1])
+    with pytest.raises(F.SonoError):
+        E.window_table(99, 512)
+
+
+def test_unknown_window_message():
+    (case,) = G.cases("plugin_window_error")
+    with pytest.raises(ValueError) as e:
+        E.window_id(case["name"])
+    assert str(e.value) == case["message"]
+
+
+def test_twiddle_tables():
+    for case in G.cases("worker_tables"):
+        n = case["N"]
+        c, s = E.twiddle_table(F.TW_ACCURATE, n)
+        for a, b in ((c, G.load(case["twiddle_cos"], np.float64)), (s, G.load(case["twiddle_sin"], np.float64))):
+            assert np.abs(a.view(np.int64) - b.view(np.int64)).max() <= 1     # libm vs V8: one ulp
+    # plugin recurrence: seeds are the float32 tables, first two entries of each stage are exact
+    for case in G.cases("plugin_tables"):
+        n = case["N"]
+        c, s = E.twiddle_table(F.TW_PLUGIN_RECURRENCE, n)
+        gs, gc = G.load(case["sin_table"], np.float32), G.load(case["cos_table"], np.float32)
+        T = 1
+        while T < n:
+            assert c[T - 1] == 1.0 and s[T - 1] == 0.0
+            if T > 1:
+                assert c[T] == float(gc[T]) and s[T] == float(gs[T])
+            T *= 2
+
+
+def test_geometry_rules():
+    for case in G.cases("plugin_get_frequencies"):
+        L = G.manifest["signals"][case["signal"]]["length"]
+        ov = E.plugin_noverlap(case["N"], case["noverlap"] or 0, L, case["canvas_width"])
+        hop = case["N"] - ov
+        g = E.geometry_for(case["N"], hop, F.FRAMES_PLUGIN_STRICT, L)
+        assert (g.frames, g.width, g.bins) == (case["frames"], case["frames"], case["bins"]), case["id"]
+    for case in G.cases("worker_render"):
+        L = G.manifest["signals"][case["signal"]]["length"]
+        n = case["N"] or 1024
+        hop = E.worker_hop(n, case["overlap"] or 0)
+        g = E.geometry_for(n, hop, F.FRAMES_WORKER_COMPAT, L)
+        assert (g.width, g.bins) == (case["width"], case["height"]), case["id"]
+        assert g.frames == ((L - n) // hop + 1 if L >= n else 0)
+    assert E.worker_hop(1024, 99.95) == 1 and E.worker_hop(1024, 0) == 1024 and E.worker_hop(1024, 75) == 256
+    assert noverlap_from_percent(1024, 75) == 768 and noverlap_from_percent(1024, None) is None
+    assert noverlap_from_percent(1024, 99) == 1013
+    with pytest.raises(F.SonoError):
+        E.geometry_for(1000, 250, 0, 5000)
+    with pytest.raises(F.SonoError):
+        E.geometry_for(1024, 0, 0, 5000)
+
+
+def test_crop_grid():
+    (case,) = G.cases("plugin_crop_grid")
+    for r in case["rows"]:
+        assert E.plugin_crop(r["N"] // 2, r["sr"], r["fmin"], r["fmax"]) == (r["sy"], r["sh"]), r
+    assert E.plugin_crop(2048, 384000, 15000, 120000) == (768, 1120)
+
+
+def test_luts():
+    for case in G.cases("plugin_render"):
+        if case["colormap"] in ("default", "rainbow"):
+            assert np.array_equal(E.plugin_lut(G.colormap(case["colormap"])), G.load(case["lut"], np.uint8))
+    for case in G.cases("worker_render"):
+        if case["colormap"]:
+            assert np.array_equal(E.worker_lut(G.colormap(case["colormap"])), G.load(case["lut"], np.uint8))
+    cm = G.colormap("default").copy()
+    cm[3, 0] = np.nan
+    cm[5, 3] = np.nan
+    lut = E.worker_lut(cm).reshape(256, 4)
+    assert lut[3, 0] == 0 and lut[5, 3] == 255
+
+
+def test_plugin_option_validation():
+    (case,) = G.cases("plugin_errors")
+    msgs = {e["label"]: e["message"] for e in case["errors"]}
+    with pytest.raises(ValueError) as e:
+        Spectrogram.create({"colorMap": [[0, 0, 0, 1]] * 10})
+    assert str(e.value) == msgs["short"]
+    with pytest.raises(ValueError) as e:
+        Spectrogram.create({"colorMap": [[0, 0, 0]] * 256})
+    assert str(e.value) == msgs["bad_entry"]
+    with pytest.raises(ValueError) as e:
+        Spectrogram.create({})
+    assert str(e.value) == msgs["default_name"]
+    with pytest.raises(ValueError) as e:
+        Spectrogram.create({"colorMap": "viridis"})
+    assert str(e.value) == msgs["unknown_name"]
+    p = Spectrogram.create({"colorMap": "gray"})
+    assert (p.fftSamples, p.height, p.noverlap, p.windowFunc, p.gainDB, p.rangeDB, p.scale) == \
+        (512, 200, None, "hann", 20, 80, "mel")
+    p = Spectrogram.create({"colorMap": "gray", "gainDB": 0, "rangeDB": 100, "noverlap": 0})
+    assert (p.gainDB, p.rangeDB, p.noverlap) == (0, 100, None)
+    q = createSpectrogramPlugin(G.colormap("default").tolist(), noverlap=768)
+    assert (q.frequencyMin, q.frequencyMax, q.scale, q.fftSamples, q.height, q.noverlap) == \
+        (10000, 128000, "linear", 1024, 800, 768)
+
+
+def test_create_without_gpu_reports_cleanly():
+    if F.lib().sono_device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(F.SonoError) as e:
+        E.Engine()
+    assert "no HIP device" in str(e.value)
+    # argument validation comes before device probing
+    with pytest.raises(F.SonoError) as e:
+        E.Engine(fft_n=1000)
+    assert str(e.value) == "Invalid buffer size, must be a power of 2."
+    with pytest.raises(F.SonoError):
+        E.Engine(hop=0)
+    with pytest.raises(F.SonoError):
+        E.Engine(window_id=77)
