@@ -25,6 +25,7 @@ struct sono_ctx {
   float* d_window = nullptr;
   void* d_tw = nullptr;       // float2[n-1] (fast) or double2[n-1] (exact)
   uint32_t* d_lut = nullptr;  // 256 packed pixels
+  void* d_fast = nullptr;     // twiddle matrix of the fast kernel (accurate twiddles only)
   bool have_lut = false;
   // host copies (sono_set_tables may replace part of them)
   std::vector<float> h_window;
@@ -190,6 +191,13 @@ sono_ctx* sono_create(int device, const sono_config* cfg) {
     sono_destroy(c);
     return nullptr;
   }
+  if (cfg->arith == SONO_ARITH_FAST_F32 && cfg->twiddle_mode == SONO_TW_ACCURATE && n == 1024) {
+    std::vector<float> t;
+    build_fast_table_1024(t);
+    if ((e = hipMalloc(&c->d_fast, sizeof(float) * t.size())) != hipSuccess) return bail("hipMalloc(fast table)", e);
+    if ((e = hipMemcpy(c->d_fast, t.data(), sizeof(float) * t.size(), hipMemcpyHostToDevice)) != hipSuccess)
+      return bail("hipMemcpy(fast table)", e);
+  }
   return c;
 }
 
@@ -197,7 +205,7 @@ void sono_destroy(sono_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
-  void* bufs[] = {c->d_window, c->d_tw, c->d_lut, c->d_in, c->d_out, c->d_aux};
+  void* bufs[] = {c->d_window, c->d_tw, c->d_lut, c->d_fast, c->d_in, c->d_out, c->d_aux};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
   if (c->ev_start) (void)hipEventDestroy(c->ev_start);
@@ -294,6 +302,7 @@ int sono_stft_async(sono_ctx* c, const void* pcm, uint64_t L, void* out, uint64_
   p.twiddles = c->d_tw;
   p.lut = c->have_lut ? c->d_lut : nullptr;
   p.out = out;
+  p.fast_table = c->d_fast;
   p.scale_mode = c->cfg.scale_mode;
   p.out_kind = c->cfg.out_kind;
   p.in_kind = c->cfg.in_kind;

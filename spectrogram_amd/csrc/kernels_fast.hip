@@ -1,16 +1,265 @@
-// Fast float32 STFT kernels (accurate twiddles).  Sizes without a specialised kernel report 1
-// and the caller falls back to the general kernel.
+// Fast float32 STFT kernel for 1024-point frames with accurate twiddles (the worker path and the
+// plugin path in "accurate" twiddle mode).
+//
+// Two real frames per complex transform: z[n] = w[n]*(xA[n] + i*xB[n]) for the frame pair (A, B);
+// after the 1024-point complex FFT the two spectra are separated with
+//     XA[k] = (Z[k] + conj Z[N-k]) / 2        XB[k] = (Z[k] - conj Z[N-k]) / (2i)
+// which costs four additions per bin pair and no twiddle.
+//
+// Mapping to CDNA4: one HALF wavefront (32 lanes) owns one complex FFT and keeps all 1024 points in
+// registers, 32 per lane.  1024 = 32 x 32, so the transform is two in-register radix-32 passes
+// (each a fully unrolled 5-stage radix-2 DIT with compile-time twiddles and the 6-FMA butterfly)
+// with one transpose through LDS in between and one more LDS round trip that brings Z[k] and
+// Z[N-k] together for the epilogue.  Each wavefront owns its slice of LDS, so the steady-state
+// loop has no workgroup barrier.  The epilogue fuses |X|^2 -> log2 -> quantiser -> packed uint8.
+//
+// LDS per 256-thread workgroup: 8 KiB twiddle matrix W_1024^(l*k1) + 8 transpose buffers of 8704 B
+// = 77824 B, i.e. two workgroups (8 wavefronts) per CU.
 #include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <vector>
 
 #include "sono_device.h"
 #include "sono_internal.h"
 
 namespace sono {
+namespace fast1024 {
+
+constexpr int kN = 1024;
+constexpr int kRowC = 34;                          // complex elements per transpose row (32 + 2 pad: rows stay 16-B aligned
+                                                   // and 16 consecutive rows start on 16 distinct 16-B bank groups)
+constexpr int kFftBufBytes = 32 * kRowC * 8;       // 8704 >= (1024 + 1) * 8
+constexpr int kWaves = 4;
+constexpr int kTwBytes = 32 * 32 * 8;
+constexpr int kLdsBytes = kTwBytes + kWaves * 2 * kFftBufBytes;
+
+// cos/sin(2*pi*j/32), j = 0..15
+__device__ constexpr float kC32[16] = {1.0f,          0.98078528040323044913f, 0.92387953251128675613f, 0.83146961230254523708f,
+                                       0.70710678118654752440f, 0.55557023301960222474f, 0.38268343236508977173f, 0.19509032201612826785f,
+                                       0.0f,          -0.19509032201612826785f, -0.38268343236508977173f, -0.55557023301960222474f,
+                                       -0.70710678118654752440f, -0.83146961230254523708f, -0.92387953251128675613f, -0.98078528040323044913f};
+__device__ constexpr float kS32[16] = {0.0f,          0.19509032201612826785f, 0.38268343236508977173f, 0.55557023301960222474f,
+                                       0.70710678118654752440f, 0.83146961230254523708f, 0.92387953251128675613f, 0.98078528040323044913f,
+                                       1.0f,          0.98078528040323044913f, 0.92387953251128675613f, 0.83146961230254523708f,
+                                       0.70710678118654752440f, 0.55557023301960222474f, 0.38268343236508977173f, 0.19509032201612826785f};
+
+__host__ __device__ constexpr int brev5(int v) {
+  return ((v & 1) << 4) | ((v & 2) << 2) | (v & 4) | ((v & 8) >> 2) | ((v & 16) >> 4);
+}
+
+// In-register 32-point forward DFT, radix-2 decimation in time.  Input in bit-reversed register
+// order, output in natural order.  All indices fold to constants after unrolling.
+__device__ __forceinline__ void fft32(float (&re)[32], float (&im)[32]) {
+#pragma unroll
+  for (int s = 0; s < 5; ++s) {
+    const int half = 1 << s;
+#pragma unroll
+    for (int g = 0; g < 32; g += 2 * half) {
+#pragma unroll
+      for (int j = 0; j < half; ++j) {
+        const int t = j * (16 >> s);  // twiddle W_32^t = (C, -S)
+        const int i0 = g + j, i1 = i0 + half;
+        const float ar = re[i0], ai = im[i0], br = re[i1], bi = im[i1];
+        if (t == 0) {
+          re[i0] = ar + br; im[i0] = ai + bi;
+          re[i1] = ar - br; im[i1] = ai - bi;
+        } else if (t == 8) {  // w = -i
+          re[i0] = ar + bi; im[i0] = ai - br;
+          re[i1] = ar - bi; im[i1] = ai + br;
+        } else {
+          const float C = kC32[t], S = kS32[t];
+          const float o1r = __builtin_fmaf(S, bi, __builtin_fmaf(C, br, ar));
+          const float o1i = __builtin_fmaf(-S, br, __builtin_fmaf(C, bi, ai));
+          re[i0] = o1r; im[i0] = o1i;
+          re[i1] = __builtin_fmaf(2.0f, ar, -o1r);
+          im[i1] = __builtin_fmaf(2.0f, ai, -o1i);
+        }
+      }
+    }
+  }
+}
+
+// Orders this wavefront's LDS traffic for the compiler.  The hardware executes one wavefront's LDS
+// instructions in issue order, so data written by one lane is visible to a later read by another
+// lane of the same wavefront without a workgroup barrier.
+__device__ __forceinline__ void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <typename In>
+__device__ __forceinline__ float ld(const In* p, int i);
+template <>
+__device__ __forceinline__ float ld<float>(const float* p, int i) {
+  return p[i];
+}
+template <>
+__device__ __forceinline__ float ld<int16_t>(const int16_t* p, int i) {
+  return (float)p[i] * (1.0f / 32768.0f);
+}
+
+// quantise |X|^2 (already including the pair-separation factor through fs.b) to a byte of `acc`
+template <bool PLUGIN, int BYTE>
+__device__ __forceinline__ uint32_t put_index(float msq, const FastScale& fs, uint32_t acc) {
+  if constexpr (PLUGIN) {
+    const uint32_t v = fast_index(msq, fs);
+    return acc | (v << (8 * BYTE));
+  } else {
+    const float t = __builtin_floorf(__builtin_fmaf(__log2f(msq), fs.a, fs.b));
+    return __builtin_amdgcn_cvt_pk_u8_f32(t, BYTE, acc);  // saturates to [0,255]; NaN -> 0
+  }
+}
+
+template <bool PLUGIN, typename In>
+__global__ __launch_bounds__(256, 2) void stft1024_u8_kernel(StftParams p, FastScale fs,
+                                                            const float2* __restrict__ tw_table) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float2* tw_lds = reinterpret_cast<float2*>(smem);
+  for (int i = threadIdx.x; i < 1024; i += 256) tw_lds[i] = tw_table[i];
+  __syncthreads();
+
+  const int lane = threadIdx.x & 63, l = lane & 31, h = lane >> 5, wave = threadIdx.x >> 6;
+  unsigned char* fbuf = smem + kTwBytes + (wave * 2 + h) * kFftBufBytes;
+  float2* tbuf = reinterpret_cast<float2*>(fbuf);  // transpose view: [k1][kRowC]
+  float2* zbuf = reinterpret_cast<float2*>(fbuf);  // spectrum view: Z[0..1024]
+
+  float win[32];
+#pragma unroll
+  for (int a = 0; a < 32; ++a) win[a] = p.window[32 * a + l];
+
+  const In* __restrict__ x = reinterpret_cast<const In*>(p.pcm);
+  uint8_t* __restrict__ out = reinterpret_cast<uint8_t*>(p.out);
+  const uint64_t npairs = (p.nframes + 1) >> 1;
+  // blocks with equal blockIdx % 8 share an XCD (and its L2): give them neighbouring frame ranges
+  const uint32_t per = gridDim.x >> 3;
+  const uint32_t vb = (gridDim.x & 7) ? blockIdx.x : (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+
+  for (uint64_t it = 0;; ++it) {
+    const uint64_t pair0 = ((it * gridDim.x + vb) * kWaves + wave) * 2;
+    if (pair0 >= npairs) break;  // wave-uniform
+    const uint64_t pair = pair0 + h;
+    const bool pair_ok = pair < npairs;
+    const uint64_t pc = pair_ok ? pair : pair0;
+    const uint64_t fa = 2 * pc;
+    const bool b_ok = (fa + 1) < p.nframes;
+    const uint64_t fb = b_ok ? fa + 1 : fa;
+    const In* xa = x + (p.frame0 + fa) * p.hop + l;
+    const In* xb = x + (p.frame0 + fb) * p.hop + l;
+
+    float re[32], im[32];
+#pragma unroll
+    for (int a = 0; a < 32; ++a) {
+      re[brev5(a)] = ld<In>(xa, 32 * a) * win[a];
+      im[brev5(a)] = ld<In>(xb, 32 * a) * win[a];
+    }
+    fft32(re, im);  // Y_l[k1]
+
+    // twiddle W_1024^(l*k1) and transpose: lane l, register k1 -> lane k1, register l
+    tbuf[l] = make_float2(re[0], im[0]);
+#pragma unroll
+    for (int k1 = 1; k1 < 32; ++k1) {
+      const float2 t = tw_lds[k1 * 32 + l];
+      const float ur = __builtin_fmaf(re[k1], t.x, -im[k1] * t.y);
+      const float ui = __builtin_fmaf(re[k1], t.y, im[k1] * t.x);
+      tbuf[k1 * kRowC + l] = make_float2(ur, ui);
+    }
+    wave_sync();
+    {
+      const float4* row = reinterpret_cast<const float4*>(tbuf + l * kRowC);
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const float4 v = row[j];
+        re[brev5(2 * j)] = v.x; im[brev5(2 * j)] = v.y;
+        re[brev5(2 * j + 1)] = v.z; im[brev5(2 * j + 1)] = v.w;
+      }
+    }
+    wave_sync();
+    fft32(re, im);  // X[l + 32*k2]
+
+    // spectrum to LDS in natural order, plus Z[1024] = Z[0] so that N-k needs no wrap
+#pragma unroll
+    for (int k2 = 0; k2 < 32; ++k2) zbuf[k2 * 32 + l] = make_float2(re[k2], im[k2]);
+    if (l == 0) zbuf[1024] = make_float2(re[0], im[0]);
+    wave_sync();
+
+    // epilogue: lane l handles bins k = 4*(l + 32*g) .. +3, g = 0..3, of both frames
+    const uint64_t rowA = (p.col0 + fa) * p.out_bins, rowB = rowA + p.out_bins;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int k = 4 * (l + 32 * g);
+      const float4 z01 = *reinterpret_cast<const float4*>(zbuf + k);
+      const float4 z23 = *reinterpret_cast<const float4*>(zbuf + k + 2);
+      const float2 p3 = zbuf[kN - k - 3], p2 = zbuf[kN - k - 2], p1 = zbuf[kN - k - 1], p0 = zbuf[kN - k];
+      uint32_t wa = 0, wb = 0;
+#define SONO_BIN(B, ZR, ZI, P)                                               \
+  {                                                                          \
+    const float ar = (ZR) + (P).x, ai = (ZI) - (P).y;                        \
+    const float br = (ZI) + (P).y, bi = (P).x - (ZR);                        \
+    wa = put_index<PLUGIN, B>(__builtin_fmaf(ar, ar, ai * ai), fs, wa);      \
+    wb = put_index<PLUGIN, B>(__builtin_fmaf(br, br, bi * bi), fs, wb);      \
+  }
+      SONO_BIN(0, z01.x, z01.y, p0)
+      SONO_BIN(1, z01.z, z01.w, p1)
+      SONO_BIN(2, z23.x, z23.y, p2)
+      SONO_BIN(3, z23.z, z23.w, p3)
+#undef SONO_BIN
+      if (k >= (int)p.bin_lo && k < (int)p.bin_hi) {
+        const uint32_t col = k - p.out_bin0;
+        if (pair_ok) *reinterpret_cast<uint32_t*>(out + rowA + col) = wa;
+        if (pair_ok && b_ok) *reinterpret_cast<uint32_t*>(out + rowB + col) = wb;
+      }
+    }
+    wave_sync();  // zbuf is rewritten by the next iteration's transpose
+  }
+}
+
+}  // namespace fast1024
+
+// W_1024^(l*k1) as [k1][l] float2 (cos, -sin), computed in double.
+void build_fast_table_1024(std::vector<float>& t) {
+  t.resize(2 * 1024);
+  const double pi = 3.141592653589793;
+  for (int k1 = 0; k1 < 32; ++k1)
+    for (int l = 0; l < 32; ++l) {
+      const double ang = -2.0 * pi * (double)(k1 * l) / 1024.0;
+      t[2 * (k1 * 32 + l)] = (float)std::cos(ang);
+      t[2 * (k1 * 32 + l) + 1] = (float)std::sin(ang);
+    }
+}
 
 int launch_stft_fast(const StftParams& p, void* stream_v) {
-  (void)p;
-  (void)stream_v;
-  return 1;
+  using namespace fast1024;
+  if (p.n != 1024 || p.out_kind != SONO_OUT_U8_INDEX || !p.fast_table) return 1;
+  if (reinterpret_cast<uintptr_t>(p.out) & 3) return 1;
+  if ((p.bin_lo & 3) || (p.bin_hi & 3) || (p.out_bins & 3) || (p.out_bin0 & 3)) return 1;
+  if (p.nframes == 0) return SONO_OK;
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_v);
+  FastScale fs = make_fast_scale(p.scale_mode, p.n, p.gain_db, p.range_db);
+  // the pair separation leaves 2*X: |2X|^2 = 4|X|^2, i.e. log2 is 2 too large
+  fs.b -= 2.0f * fs.a;
+  fs.db_off -= 2.0f * 3.0102999566f;
+  const uint64_t npairs = (p.nframes + 1) / 2;
+  const uint64_t need = (npairs + 2 * kWaves - 1) / (2 * kWaves);
+  const uint32_t grid = (uint32_t)(need < 2048 ? need : 2048);
+  const float2* table = reinterpret_cast<const float2*>(p.fast_table);
+#define SONO_LAUNCH(PLUGIN, In)                                                                             \
+  do {                                                                                                      \
+    auto kern = stft1024_u8_kernel<PLUGIN, In>;                                                             \
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                            kLdsBytes) != hipSuccess)                                                       \
+      return SONO_ERR_DEVICE;                                                                               \
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), kLdsBytes, stream, p, fs, table);                       \
+  } while (0)
+  const bool plugin = p.scale_mode == SONO_SCALE_PLUGIN_DB;
+  if (p.in_kind == SONO_IN_I16) {
+    if (plugin) SONO_LAUNCH(true, int16_t); else SONO_LAUNCH(false, int16_t);
+  } else {
+    if (plugin) SONO_LAUNCH(true, float); else SONO_LAUNCH(false, float);
+  }
+#undef SONO_LAUNCH
+  return hipGetLastError() == hipSuccess ? SONO_OK : SONO_ERR_DEVICE;
 }
 
 }  // namespace sono

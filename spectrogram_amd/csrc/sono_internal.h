@@ -4,6 +4,8 @@
 
 #include <stdint.h>
 
+#include <vector>
+
 #include "sonospec.h"
 
 namespace sono {
@@ -32,6 +34,7 @@ struct StftParams {
   const void* twiddles;   // device, n-1 float2 (fast) or double2 (exact), flat stage layout
   const uint32_t* lut;    // device, 256 packed RGBA (little endian r | g<<8 | b<<16 | a<<24), or nullptr = grey
   void* out;              // device
+  const void* fast_table; // device: per-size twiddle matrix of the fast kernels, or nullptr
   uint32_t scale_mode, out_kind, in_kind;
   double gain_db, range_db;
 };
@@ -40,6 +43,7 @@ struct StftParams {
 int launch_stft_general(const StftParams& p, bool exact_f64, void* hip_stream);
 // kernels_fast.hip: float32 kernels with accurate twiddles (returns 1 if this size/mode has no fast kernel).
 int launch_stft_fast(const StftParams& p, void* hip_stream);
+void build_fast_table_1024(std::vector<float>& t);
 // kernels_post.hip
 int launch_resample(const uint8_t* in, uint64_t in_frames, uint32_t bins, uint64_t out_width, uint8_t* out,
                     void* hip_stream);
