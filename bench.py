@@ -90,9 +90,9 @@ def main():
         torch.cuda.synchronize()
 
     L = args.seconds * SAMPLE_RATE
-    # ---- synthetic recording, generated on the device in 10 s blocks
+    # ---- synthetic recording, generated on the device in 300 s blocks
     x = torch.empty(L, dtype=torch.float32, device=dev)
-    blk = 10 * SAMPLE_RATE
+    blk = 300 * SAMPLE_RATE
     for s in range(0, L, blk):
         c = min(blk, L - s)
         x[s:s + c] = synth_chunk(torch, dev, s, c, 12345 + rank * 1000 + s // blk)
