@@ -13,8 +13,11 @@
 // Z[N-k] together for the epilogue.  Each wavefront owns its slice of LDS, so the steady-state
 // loop has no workgroup barrier.  The epilogue fuses |X|^2 -> log2 -> quantiser -> packed uint8.
 //
-// LDS per 256-thread workgroup: 8 KiB twiddle matrix W_1024^(l*k1) + 8 transpose buffers of 8704 B
-// = 77824 B, i.e. two workgroups (8 wavefronts) per CU.
+// Occupancy is what this kernel lives on (one wavefront issues at most one VALU instruction per four
+// cycles and waits on LDS about half the time), so the per-wavefront LDS slice is kept at 9 KiB: the
+// transpose moves the real and the imaginary plane one after the other through the same 4.5 KiB
+// buffer and the epilogue handles the bins in two halves.  One 1024-thread workgroup (16 independent
+// wavefronts = 4 per SIMD, <= 128 VGPRs) per CU: 8 KiB twiddle matrix W_1024^(l*k1) + 4.5 KiB window + 32 x 4608 B.
 #include <hip/hip_runtime.h>
 
 #include <cmath>
@@ -27,12 +30,16 @@ namespace sono {
 namespace fast1024 {
 
 constexpr int kN = 1024;
-constexpr int kRowC = 34;                          // complex elements per transpose row (32 + 2 pad: rows stay 16-B aligned
-                                                   // and 16 consecutive rows start on 16 distinct 16-B bank groups)
-constexpr int kFftBufBytes = 32 * kRowC * 8;       // 8704 >= (1024 + 1) * 8
-constexpr int kWaves = 4;
+constexpr int kThreads = 1024;                     // 16 independent wavefronts share one twiddle matrix
+constexpr int kWaves = kThreads / 64;
+constexpr int kPlaneStride = 36;                   // floats per transpose row: rows stay 16-B aligned and 16 consecutive
+                                                   // rows start on 16 distinct 4-bank groups (ds_read_b128 conflict-free)
+constexpr int kFftBufBytes = 32 * kPlaneStride * 4;  // 4608: one plane of the transpose, or one half of the epilogue
+constexpr int kMirrorOffset = 256 * 8;             // epilogue: Z[k] in [0, 2048), Z[N-k] in [2048, 2048 + 257*8)
+static_assert(kMirrorOffset + 257 * 8 <= kFftBufBytes, "epilogue half must fit the transpose buffer");
 constexpr int kTwBytes = 32 * 32 * 8;
-constexpr int kLdsBytes = kTwBytes + kWaves * 2 * kFftBufBytes;
+constexpr int kWinBytes = 32 * kPlaneStride * 4;   // window as [l][kPlaneStride]: lane l reads w[32a + l], a = 0..31, as 8 x 16 B
+constexpr int kLdsBytes = kTwBytes + kWinBytes + kWaves * 2 * kFftBufBytes;  // 160256: one workgroup per CU
 
 // cos/sin(2*pi*j/32), j = 0..15
 __device__ constexpr float kC32[16] = {1.0f,          0.98078528040323044913f, 0.92387953251128675613f, 0.83146961230254523708f,
@@ -112,22 +119,26 @@ __device__ __forceinline__ uint32_t put_index(float msq, const FastScale& fs, ui
   }
 }
 
-template <bool PLUGIN, typename In>
-__global__ __launch_bounds__(256, 2) void stft1024_u8_kernel(StftParams p, FastScale fs,
-                                                            const float2* __restrict__ tw_table) {
+// HOP32 > 0: hop == 32*HOP32, so frame B's sample 32a+l is frame A's sample 32(a+HOP32)+l and one
+// run of 32+HOP32 loads feeds both frames.  HOP32 == 0: any hop, two runs of 32 loads.
+template <bool PLUGIN, typename In, int HOP32>
+__global__ __launch_bounds__(kThreads, kThreads / 256) void stft1024_u8_kernel(StftParams p, FastScale fs,
+                                                                             const float2* __restrict__ tw_table) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float2* tw_lds = reinterpret_cast<float2*>(smem);
-  for (int i = threadIdx.x; i < 1024; i += 256) tw_lds[i] = tw_table[i];
+  float* win_lds = reinterpret_cast<float*>(smem + kTwBytes);
+  for (int i = threadIdx.x; i < 1024; i += kThreads) {
+    tw_lds[i] = tw_table[i];
+    win_lds[(i & 31) * kPlaneStride + (i >> 5)] = p.window[i];  // sample n = 32a + l at [l][a]
+  }
   __syncthreads();
 
   const int lane = threadIdx.x & 63, l = lane & 31, h = lane >> 5, wave = threadIdx.x >> 6;
-  unsigned char* fbuf = smem + kTwBytes + (wave * 2 + h) * kFftBufBytes;
-  float2* tbuf = reinterpret_cast<float2*>(fbuf);  // transpose view: [k1][kRowC]
-  float2* zbuf = reinterpret_cast<float2*>(fbuf);  // spectrum view: Z[0..1024]
-
-  float win[32];
-#pragma unroll
-  for (int a = 0; a < 32; ++a) win[a] = p.window[32 * a + l];
+  unsigned char* fbuf = smem + kTwBytes + kWinBytes + (wave * 2 + h) * kFftBufBytes;
+  const float4* win_row = reinterpret_cast<const float4*>(win_lds + l * kPlaneStride);
+  float* plane = reinterpret_cast<float*>(fbuf);                   // transpose view: [k1][kPlaneStride] floats
+  float2* lbuf = reinterpret_cast<float2*>(fbuf);                  // epilogue view: Z[k], 256 entries
+  float2* mbuf = reinterpret_cast<float2*>(fbuf + kMirrorOffset);  // epilogue view: Z[N-k], 257 entries
 
   const In* __restrict__ x = reinterpret_cast<const In*>(p.pcm);
   uint8_t* __restrict__ out = reinterpret_cast<uint8_t*>(p.out);
@@ -140,78 +151,126 @@ __global__ __launch_bounds__(256, 2) void stft1024_u8_kernel(StftParams p, FastS
     const uint64_t pair0 = ((it * gridDim.x + vb) * kWaves + wave) * 2;
     if (pair0 >= npairs) break;  // wave-uniform
     const uint64_t pair = pair0 + h;
-    const bool pair_ok = pair < npairs;
-    const uint64_t pc = pair_ok ? pair : pair0;
-    const uint64_t fa = 2 * pc;
-    const bool b_ok = (fa + 1) < p.nframes;
-    const uint64_t fb = b_ok ? fa + 1 : fa;
-    const In* xa = x + (p.frame0 + fa) * p.hop + l;
-    const In* xb = x + (p.frame0 + fb) * p.hop + l;
+    // frames (f0, f0+1) form the complex input; st_a / st_b say which of the two results are stored.
+    // An odd last frame is computed as the second member of the pair before it.
+    uint64_t f0 = 2 * pair;
+    bool st_a = pair < npairs, st_b = st_a;
+    if (!st_a) {
+      f0 = 2 * pair0;
+    } else if (f0 + 1 >= p.nframes) {
+      f0 -= 1;
+      st_a = false;
+    }
+    const In* xa = x + (p.frame0 + f0) * p.hop + l;
 
     float re[32], im[32];
+    float win[32];
 #pragma unroll
-    for (int a = 0; a < 32; ++a) {
-      re[brev5(a)] = ld<In>(xa, 32 * a) * win[a];
-      im[brev5(a)] = ld<In>(xb, 32 * a) * win[a];
+    for (int j = 0; j < 8; ++j) {
+      const float4 v = win_row[j];
+      win[4 * j] = v.x; win[4 * j + 1] = v.y; win[4 * j + 2] = v.z; win[4 * j + 3] = v.w;
+    }
+    if constexpr (HOP32 > 0) {
+      float raw[32 + HOP32];
+#pragma unroll
+      for (int a = 0; a < 32 + HOP32; ++a) raw[a] = ld<In>(xa, 32 * a);
+#pragma unroll
+      for (int a = 0; a < 32; ++a) {
+        re[brev5(a)] = raw[a] * win[a];
+        im[brev5(a)] = raw[a + HOP32] * win[a];
+      }
+    } else {
+      const In* xb = xa + p.hop;
+#pragma unroll
+      for (int a = 0; a < 32; ++a) {
+        re[brev5(a)] = ld<In>(xa, 32 * a) * win[a];
+        im[brev5(a)] = ld<In>(xb, 32 * a) * win[a];
+      }
     }
     fft32(re, im);  // Y_l[k1]
 
-    // twiddle W_1024^(l*k1) and transpose: lane l, register k1 -> lane k1, register l
-    tbuf[l] = make_float2(re[0], im[0]);
+    // twiddle W_1024^(l*k1), then transpose lane l, register k1 -> lane k1, register l; the real and
+    // the imaginary plane go through the same LDS buffer one after the other
 #pragma unroll
     for (int k1 = 1; k1 < 32; ++k1) {
       const float2 t = tw_lds[k1 * 32 + l];
       const float ur = __builtin_fmaf(re[k1], t.x, -im[k1] * t.y);
       const float ui = __builtin_fmaf(re[k1], t.y, im[k1] * t.x);
-      tbuf[k1 * kRowC + l] = make_float2(ur, ui);
+      re[k1] = ur;
+      im[k1] = ui;
     }
+#pragma unroll
+    for (int k1 = 0; k1 < 32; ++k1) plane[k1 * kPlaneStride + l] = re[k1];
     wave_sync();
     {
-      const float4* row = reinterpret_cast<const float4*>(tbuf + l * kRowC);
+      const float4* row = reinterpret_cast<const float4*>(plane + l * kPlaneStride);
 #pragma unroll
-      for (int j = 0; j < 16; ++j) {
+      for (int j = 0; j < 8; ++j) {
         const float4 v = row[j];
-        re[brev5(2 * j)] = v.x; im[brev5(2 * j)] = v.y;
-        re[brev5(2 * j + 1)] = v.z; im[brev5(2 * j + 1)] = v.w;
+        re[brev5(4 * j)] = v.x; re[brev5(4 * j + 1)] = v.y; re[brev5(4 * j + 2)] = v.z; re[brev5(4 * j + 3)] = v.w;
+      }
+    }
+    wave_sync();
+#pragma unroll
+    for (int k1 = 0; k1 < 32; ++k1) plane[k1 * kPlaneStride + l] = im[k1];
+    wave_sync();
+    {
+      const float4* row = reinterpret_cast<const float4*>(plane + l * kPlaneStride);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float4 v = row[j];
+        im[brev5(4 * j)] = v.x; im[brev5(4 * j + 1)] = v.y; im[brev5(4 * j + 2)] = v.z; im[brev5(4 * j + 3)] = v.w;
       }
     }
     wave_sync();
     fft32(re, im);  // X[l + 32*k2]
 
-    // spectrum to LDS in natural order, plus Z[1024] = Z[0] so that N-k needs no wrap
+    // Epilogue in two halves of 256 bins.  For half P the registers k2 in [8P, 8P+8) hold Z[k] for
+    // k = 256P .. 256P+255 and the registers k2 in [24-8P, 32-8P) hold the partners Z[N-k]; both are
+    // laid out ascending in k (lbuf[k - 256P], mbuf[k - 256P]) so that four consecutive bins are two
+    // aligned 16-byte reads each.  Lane 0's registers sit one row off (k1 = 0), so it also supplies
+    // mbuf[0] (Z[N - 256P] = Z[0] or Z[768]).
+    const uint64_t row_a = (p.col0 + f0) * p.out_bins, row_b = row_a + p.out_bins;
 #pragma unroll
-    for (int k2 = 0; k2 < 32; ++k2) zbuf[k2 * 32 + l] = make_float2(re[k2], im[k2]);
-    if (l == 0) zbuf[1024] = make_float2(re[0], im[0]);
-    wave_sync();
-
-    // epilogue: lane l handles bins k = 4*(l + 32*g) .. +3, g = 0..3, of both frames
-    const uint64_t rowA = (p.col0 + fa) * p.out_bins, rowB = rowA + p.out_bins;
+    for (int P = 0; P < 2; ++P) {
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const int k = 4 * (l + 32 * g);
-      const float4 z01 = *reinterpret_cast<const float4*>(zbuf + k);
-      const float4 z23 = *reinterpret_cast<const float4*>(zbuf + k + 2);
-      const float2 p3 = zbuf[kN - k - 3], p2 = zbuf[kN - k - 2], p1 = zbuf[kN - k - 1], p0 = zbuf[kN - k];
-      uint32_t wa = 0, wb = 0;
-#define SONO_BIN(B, ZR, ZI, P)                                               \
+      for (int r = 0; r < 8; ++r) {
+        const int kl = 8 * P + r;        // Z[k1 + 32*kl]        -> lbuf[32*r + k1]
+        const int km = 24 - 8 * P + r;   // Z[k1 + 32*km] = Z[N - j], j = 32*(7 - r) + 32 - k1 (+256P)
+        lbuf[32 * r + l] = make_float2(re[kl], im[kl]);
+        mbuf[32 * (7 - r) + 32 - l] = make_float2(re[km], im[km]);
+      }
+      if (l == 0) mbuf[0] = make_float2(re[P ? 24 : 0], im[P ? 24 : 0]);
+      wave_sync();
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {
+        const int idx = 4 * (l + 32 * g);
+        const int k = 256 * P + idx;
+        const float4 z01 = *reinterpret_cast<const float4*>(lbuf + idx);
+        const float4 z23 = *reinterpret_cast<const float4*>(lbuf + idx + 2);
+        const float4 q01 = *reinterpret_cast<const float4*>(mbuf + idx);
+        const float4 q23 = *reinterpret_cast<const float4*>(mbuf + idx + 2);
+        uint32_t wa = 0, wb = 0;
+#define SONO_BIN(B, ZR, ZI, PR, PI)                                          \
   {                                                                          \
-    const float ar = (ZR) + (P).x, ai = (ZI) - (P).y;                        \
-    const float br = (ZI) + (P).y, bi = (P).x - (ZR);                        \
+    const float ar = (ZR) + (PR), ai = (ZI) - (PI);                          \
+    const float br = (ZI) + (PI), bi = (PR) - (ZR);                          \
     wa = put_index<PLUGIN, B>(__builtin_fmaf(ar, ar, ai * ai), fs, wa);      \
     wb = put_index<PLUGIN, B>(__builtin_fmaf(br, br, bi * bi), fs, wb);      \
   }
-      SONO_BIN(0, z01.x, z01.y, p0)
-      SONO_BIN(1, z01.z, z01.w, p1)
-      SONO_BIN(2, z23.x, z23.y, p2)
-      SONO_BIN(3, z23.z, z23.w, p3)
+        SONO_BIN(0, z01.x, z01.y, q01.x, q01.y)
+        SONO_BIN(1, z01.z, z01.w, q01.z, q01.w)
+        SONO_BIN(2, z23.x, z23.y, q23.x, q23.y)
+        SONO_BIN(3, z23.z, z23.w, q23.z, q23.w)
 #undef SONO_BIN
-      if (k >= (int)p.bin_lo && k < (int)p.bin_hi) {
-        const uint32_t col = k - p.out_bin0;
-        if (pair_ok) *reinterpret_cast<uint32_t*>(out + rowA + col) = wa;
-        if (pair_ok && b_ok) *reinterpret_cast<uint32_t*>(out + rowB + col) = wb;
+        if (k >= (int)p.bin_lo && k < (int)p.bin_hi) {
+          const uint32_t col = k - p.out_bin0;
+          if (st_a) *reinterpret_cast<uint32_t*>(out + row_a + col) = wa;
+          if (st_b) *reinterpret_cast<uint32_t*>(out + row_b + col) = wb;
+        }
       }
+      wave_sync();  // the buffer is rewritten by the next half / the next iteration's transpose
     }
-    wave_sync();  // zbuf is rewritten by the next iteration's transpose
   }
 }
 
@@ -234,7 +293,7 @@ int launch_stft_fast(const StftParams& p, void* stream_v) {
   if (p.n != 1024 || p.out_kind != SONO_OUT_U8_INDEX || !p.fast_table) return 1;
   if (reinterpret_cast<uintptr_t>(p.out) & 3) return 1;
   if ((p.bin_lo & 3) || (p.bin_hi & 3) || (p.out_bins & 3) || (p.out_bin0 & 3)) return 1;
-  if (p.nframes == 0) return SONO_OK;
+  if (p.nframes < 16) return 1;  // a handful of frames (e.g. the worker's wrapped last frame): general kernel
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_v);
   FastScale fs = make_fast_scale(p.scale_mode, p.n, p.gain_db, p.range_db);
   // the pair separation leaves 2*X: |2X|^2 = 4|X|^2, i.e. log2 is 2 too large
@@ -242,15 +301,28 @@ int launch_stft_fast(const StftParams& p, void* stream_v) {
   fs.db_off -= 2.0f * 3.0102999566f;
   const uint64_t npairs = (p.nframes + 1) / 2;
   const uint64_t need = (npairs + 2 * kWaves - 1) / (2 * kWaves);
-  const uint32_t grid = (uint32_t)(need < 2048 ? need : 2048);
+  int cus = 256;
+  {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+      cus = prop.multiProcessorCount;
+  }
+  const uint32_t grid = (uint32_t)(need < (uint64_t)cus ? need : (uint64_t)cus);  // persistent: one workgroup per CU
   const float2* table = reinterpret_cast<const float2*>(p.fast_table);
-#define SONO_LAUNCH(PLUGIN, In)                                                                             \
+#define SONO_LAUNCH_H(PLUGIN, In, H)                                                                        \
   do {                                                                                                      \
-    auto kern = stft1024_u8_kernel<PLUGIN, In>;                                                             \
+    auto kern = stft1024_u8_kernel<PLUGIN, In, H>;                                                          \
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, \
                             kLdsBytes) != hipSuccess)                                                       \
       return SONO_ERR_DEVICE;                                                                               \
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), kLdsBytes, stream, p, fs, table);                       \
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), kLdsBytes, stream, p, fs, table);                  \
+  } while (0)
+#define SONO_LAUNCH(PLUGIN, In)                                                                             \
+  do {                                                                                                      \
+    if (p.hop == 256) SONO_LAUNCH_H(PLUGIN, In, 8);                                                         \
+    else if (p.hop == 512) SONO_LAUNCH_H(PLUGIN, In, 16);                                                   \
+    else SONO_LAUNCH_H(PLUGIN, In, 0);                                                                      \
   } while (0)
   const bool plugin = p.scale_mode == SONO_SCALE_PLUGIN_DB;
   if (p.in_kind == SONO_IN_I16) {
@@ -259,6 +331,7 @@ int launch_stft_fast(const StftParams& p, void* stream_v) {
     if (plugin) SONO_LAUNCH(true, float); else SONO_LAUNCH(false, float);
   }
 #undef SONO_LAUNCH
+#undef SONO_LAUNCH_H
   return hipGetLastError() == hipSuccess ? SONO_OK : SONO_ERR_DEVICE;
 }
 
