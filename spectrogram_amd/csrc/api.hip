@@ -314,6 +314,37 @@ int sono_stft_async(sono_ctx* c, const void* pcm, uint64_t L, void* out, uint64_
   auto launch = [&](const StftParams& q) -> int {
     if ((q.frame0 + q.nframes - 1) * q.hop + q.n > q.n_samples) return fail(c, SONO_ERR_ARG, "frame range exceeds the signal");
     int r = 1;
+    if (fast_eligible(c) && q.out_kind == SONO_OUT_RGBA8 && q.row_of_bin0 == (int32_t)q.bin_hi - 1) {
+      // RGBA through the fast kernel: colour indices of a chunk of frames go to a context-owned
+      // [frame][bin] buffer small enough to stay in the Infinity Cache, then a transposing LUT
+      // kernel writes the chunk's image columns.
+      StftParams u = q;
+      u.out_kind = SONO_OUT_U8_INDEX;
+      u.out_bins = q.bin_hi - q.bin_lo;
+      u.out_bin0 = q.bin_lo;
+      if (fast_u8_available(u)) {
+        const uint64_t nb = u.out_bins;
+        const uint64_t chunk = ((uint64_t)96 << 20) / nb / 64 * 64;   // frames per chunk (96 MiB of indices)
+        int rc2 = ensure(c, &c->d_aux, &c->d_aux_bytes, (q.nframes < chunk ? q.nframes : chunk) * nb);
+        if (rc2 != SONO_OK) return rc2;
+        for (uint64_t f = 0; f < q.nframes; f += chunk) {
+          u.frame0 = q.frame0 + f;
+          u.nframes = (q.nframes - f < chunk) ? q.nframes - f : chunk;
+          u.col0 = 0;
+          u.out = c->d_aux;
+          if (u.nframes < 16) {
+            r = launch_stft_general(u, false, c->stream);
+          } else {
+            r = launch_stft_fast(u, c->stream);
+          }
+          if (r != SONO_OK) return fail(c, r, "kernel launch failed: %s", hipGetErrorString(hipGetLastError()));
+          r = launch_colorize((const uint8_t*)c->d_aux, u.nframes, (uint32_t)nb, 0, (uint32_t)nb, q.lut, (uint8_t*)q.out,
+                              q.width, q.col0 + f, c->stream);
+          if (r != SONO_OK) return fail(c, r, "colorize launch failed");
+        }
+        return SONO_OK;
+      }
+    }
     if (fast_eligible(c)) r = launch_stft_fast(q, c->stream);
     if (r == 1) r = launch_stft_general(q, c->cfg.arith == SONO_ARITH_EXACT_F64, c->stream);
     if (r != SONO_OK) return fail(c, r, "kernel launch failed: %s", hipGetErrorString(hipGetLastError()));
@@ -427,7 +458,7 @@ int sono_colorize(sono_ctx* c, const uint8_t* frames, uint64_t width, uint32_t b
     din = (const uint8_t*)c->d_aux;
     dout = (uint8_t*)c->d_out;
   }
-  int rc = launch_colorize(din, width, bins, row0, rows, c->have_lut ? c->d_lut : nullptr, dout, c->stream);
+  int rc = launch_colorize(din, width, bins, row0, rows, c->have_lut ? c->d_lut : nullptr, dout, width, 0, c->stream);
   if (rc != SONO_OK) return fail(c, rc, "colorize launch failed");
   if (mem == SONO_MEM_HOST && out_bytes) HIP_TRY(c, hipMemcpyAsync(rgba, dout, out_bytes, hipMemcpyDeviceToHost, c->stream));
   return sono_wait(c);

@@ -288,12 +288,17 @@ void build_fast_table_1024(std::vector<float>& t) {
     }
 }
 
+bool fast_u8_available(const StftParams& p) {
+  if (p.n != 1024 || !p.fast_table) return false;
+  if ((p.bin_lo & 3) || (p.bin_hi & 3) || (p.out_bins & 3) || (p.out_bin0 & 3)) return false;
+  if (p.nframes < 16) return false;  // a handful of frames (e.g. the worker's wrapped last frame): general kernel
+  return true;
+}
+
 int launch_stft_fast(const StftParams& p, void* stream_v) {
   using namespace fast1024;
-  if (p.n != 1024 || p.out_kind != SONO_OUT_U8_INDEX || !p.fast_table) return 1;
+  if (p.out_kind != SONO_OUT_U8_INDEX || !fast_u8_available(p)) return 1;
   if (reinterpret_cast<uintptr_t>(p.out) & 3) return 1;
-  if ((p.bin_lo & 3) || (p.bin_hi & 3) || (p.out_bins & 3) || (p.out_bin0 & 3)) return 1;
-  if (p.nframes < 16) return 1;  // a handful of frames (e.g. the worker's wrapped last frame): general kernel
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_v);
   FastScale fs = make_fast_scale(p.scale_mode, p.n, p.gain_db, p.range_db);
   // the pair separation leaves 2*X: |2X|^2 = 4|X|^2, i.e. log2 is 2 too large

@@ -52,47 +52,72 @@ int launch_resample(const uint8_t* in, uint64_t F, uint32_t bins, uint64_t W, ui
 // LUT + vertical flip (+ row window), spectrogram.esm.js:366-380.  frames is [width][bins];
 // image row r holds bin bins-1-r.  A 64x64 tile goes through LDS so that both the byte reads
 // (along bins) and the pixel writes (along columns) are contiguous.
-constexpr int kTile = 64;
+// Tile: 256 columns (frames) x 64 image rows.  Every image row gets a 1-KiB run of pixels per
+// tile (one wavefront-wide 16-B-per-lane store), which keeps DRAM pages open on the write side -- the
+// image rows are tens of megabytes apart; the uint8 source is read 64 B per frame, but it is small
+// and usually still cache-resident.
+constexpr int kTileCols = 256, kTileRows = 64, kTileStride = kTileRows + 4;
 
-__global__ __launch_bounds__(256) void colorize_kernel(const uint8_t* __restrict__ frames, uint64_t width, uint32_t bins,
+// frames: [ncols][bins] uint8.  Image: `rows` rows of `img_width` pixels; this call fills columns
+// [col0, col0 + ncols).  Image row r holds bin bins-1-(row0+r).
+__global__ __launch_bounds__(256) void colorize_kernel(const uint8_t* __restrict__ frames, uint64_t ncols, uint32_t bins,
                                                       uint32_t row0, uint32_t rows, const uint32_t* __restrict__ lut,
-                                                      uint32_t* __restrict__ rgba) {
-  __shared__ uint8_t tile[kTile][kTile + 4];
-  const uint64_t t0 = (uint64_t)blockIdx.x * kTile;  // first column of the tile
-  const uint32_t r0 = blockIdx.y * kTile;            // first output row of the tile (relative to row0)
-  const uint32_t tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-  // read: thread tx walks bins (contiguous bytes of one frame)
-  for (uint32_t c = ty; c < kTile; c += 4) {
-    const uint64_t t = t0 + c;
-    const uint32_t r = r0 + tx;  // output row (relative)
-    uint8_t v = 0;
-    if (t < width && r < rows) {
-      const uint32_t e = bins - 1 - (row0 + r);
-      v = frames[t * bins + e];
+                                                      uint32_t* __restrict__ rgba, uint64_t img_width, uint64_t col0,
+                                                      int aligned4) {
+  __shared__ __attribute__((aligned(16))) uint8_t tile[kTileCols * kTileStride];  // [column][bin - e_lo]
+  const uint64_t t0 = (uint64_t)blockIdx.x * kTileCols;
+  const uint32_t r0 = blockIdx.y * kTileRows;               // first image row of the tile (relative to row0)
+  const uint32_t nrows = min((uint32_t)kTileRows, rows - r0);
+  const uint32_t ncol = (uint32_t)min((uint64_t)kTileCols, ncols - t0);
+  // image rows r0 .. r0+nrows-1 are bins e_hi-1 .. e_lo (descending); the tile stores bin e at [e - e_lo]
+  const uint32_t e_hi = bins - (row0 + r0);
+  const uint32_t e_lo = e_hi - nrows;
+  const uint32_t tid = threadIdx.x;
+  if (aligned4 && nrows == kTileRows) {
+    // 16 threads read one frame's 64 bins as dwords
+    for (uint32_t c = tid >> 4; c < ncol; c += 16) {
+      const uint32_t v = *reinterpret_cast<const uint32_t*>(frames + (t0 + c) * bins + e_lo + 4 * (tid & 15));
+      *reinterpret_cast<uint32_t*>(tile + c * kTileStride + 4 * (tid & 15)) = v;
     }
-    tile[c][tx] = v;
+  } else {
+    for (uint32_t i = tid; i < ncol * nrows; i += 256) {
+      const uint32_t c = i / nrows, e = i - c * nrows;
+      tile[c * kTileStride + e] = frames[(t0 + c) * bins + e_lo + e];
+    }
   }
   __syncthreads();
-  // write: thread tx walks columns (contiguous pixels of one image row)
-  for (uint32_t rr = ty; rr < kTile; rr += 4) {
-    const uint32_t r = r0 + rr;
-    const uint64_t t = t0 + tx;
-    if (t < width && r < rows) {
-      const uint32_t idx = tile[tx][rr];
-      rgba[(uint64_t)r * width + t] = lut ? lut[idx] : (idx | (idx << 8) | (idx << 16) | 0xff000000u);
+  // one wavefront per image row, 4 consecutive columns per lane
+  const uint32_t q = tid & 63;
+  for (uint32_t rr = tid >> 6; rr < nrows; rr += 4) {
+    const uint32_t e = nrows - 1 - rr;  // bin offset in the tile
+    uint32_t px[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const uint32_t idx = tile[(4 * q + j) * kTileStride + e];
+      px[j] = lut ? lut[idx] : (idx | (idx << 8) | (idx << 16) | 0xff000000u);
+    }
+    uint32_t* dst = rgba + (uint64_t)(r0 + rr) * img_width + col0 + t0 + 4 * q;
+    if (4 * q + 3 < ncol && ((reinterpret_cast<uintptr_t>(dst) & 15) == 0)) {
+      *reinterpret_cast<uint4*>(dst) = make_uint4(px[0], px[1], px[2], px[3]);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (4 * q + j < ncol) dst[j] = px[j];
     }
   }
 }
 
-int launch_colorize(const uint8_t* frames, uint64_t width, uint32_t bins, uint32_t row0, uint32_t rows,
-                    const uint32_t* lut, uint8_t* rgba, void* stream_v) {
-  if (width == 0 || rows == 0) return SONO_OK;
+int launch_colorize(const uint8_t* frames, uint64_t ncols, uint32_t bins, uint32_t row0, uint32_t rows,
+                    const uint32_t* lut, uint8_t* rgba, uint64_t img_width, uint64_t col0, void* stream_v) {
+  if (ncols == 0 || rows == 0) return SONO_OK;
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_v);
-  const uint64_t gx = (width + kTile - 1) / kTile;
-  const uint32_t gy = (rows + kTile - 1) / kTile;
+  const uint64_t gx = (ncols + kTileCols - 1) / kTileCols;
+  const uint32_t gy = (rows + kTileRows - 1) / kTileRows;
   if (gx > 0x7fffffffull || gy > 65535u) return SONO_ERR_ARG;
-  hipLaunchKernelGGL(colorize_kernel, dim3((uint32_t)gx, gy), dim3(256), 0, stream, frames, width, bins, row0, rows,
-                     lut, reinterpret_cast<uint32_t*>(rgba));
+  // dword reads need every tile's first bin and the frame stride to be multiples of four
+  const int aligned4 = ((bins & 3) == 0 && ((bins - row0) & 3) == 0 && (reinterpret_cast<uintptr_t>(frames) & 3) == 0) ? 1 : 0;
+  hipLaunchKernelGGL(colorize_kernel, dim3((uint32_t)gx, gy), dim3(256), 0, stream, frames, ncols, bins, row0, rows,
+                     lut, reinterpret_cast<uint32_t*>(rgba), img_width, col0, aligned4);
   return hipGetLastError() == hipSuccess ? SONO_OK : SONO_ERR_DEVICE;
 }
 

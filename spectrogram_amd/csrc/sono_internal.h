@@ -47,8 +47,10 @@ void build_fast_table_1024(std::vector<float>& t);
 // kernels_post.hip
 int launch_resample(const uint8_t* in, uint64_t in_frames, uint32_t bins, uint64_t out_width, uint8_t* out,
                     void* hip_stream);
-int launch_colorize(const uint8_t* frames, uint64_t width, uint32_t bins, uint32_t row0, uint32_t rows,
-                    const uint32_t* lut, uint8_t* rgba, void* hip_stream);
+int launch_colorize(const uint8_t* frames, uint64_t ncols, uint32_t bins, uint32_t row0, uint32_t rows,
+                    const uint32_t* lut, uint8_t* rgba, uint64_t img_width, uint64_t col0, void* hip_stream);
+// True when launch_stft_fast has a kernel for this size / layout with uint8 output.
+bool fast_u8_available(const StftParams& p);
 int launch_frame_peaks(const uint8_t* idx, uint64_t frames, uint32_t bins, int32_t* peak_bin, uint8_t* peak_idx,
                        void* hip_stream);
 
