@@ -1,0 +1,569 @@
+/*
+ * sonospec_napi.c -- Node.js N-API addon over the C ABI of libsonospec.so (include/sonospec.h).
+ *
+ * Thin by design: every export is one C-ABI call with typed-array arguments.  The JavaScript side
+ * (index.js, spectrogram_plugin.js, spectrogram_worker.js) carries the reference's interfaces.
+ * Plain C against node_api.h (N-API 3 or later); no C++ wrapper library is needed.
+ */
+#include <node_api.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "sonospec.h"
+
+#define NAPI_OK(env, call)                                                  \
+  do {                                                                      \
+    if ((call) != napi_ok) {                                                \
+      napi_throw_error((env), NULL, "N-API call failed: " #call);           \
+      return NULL;                                                          \
+    }                                                                       \
+  } while (0)
+
+/* argv holds up to 8 values; argc is clamped to that (napi_get_cb_info reports the real count) */
+#define ARGS(env, info, n)                                                  \
+  size_t argc = 8;                                                          \
+  napi_value argv[8];                                                       \
+  NAPI_OK(env, napi_get_cb_info((env), (info), &argc, argv, NULL, NULL));   \
+  if (argc > 8) argc = 8;                                                   \
+  if (argc < (n)) {                                                         \
+    napi_throw_type_error((env), NULL, "too few arguments");                \
+    return NULL;                                                            \
+  }
+
+static napi_value throw_msg(napi_env env, const char* msg) {
+  napi_throw_error(env, NULL, msg);
+  return NULL;
+}
+
+static int get_u32(napi_env env, napi_value v, uint32_t* out) {
+  double d;
+  if (napi_get_value_double(env, v, &d) != napi_ok) return 0;
+  *out = (uint32_t)d;
+  return 1;
+}
+static int get_f64(napi_env env, napi_value v, double* out) { return napi_get_value_double(env, v, out) == napi_ok; }
+static int get_u64(napi_env env, napi_value v, uint64_t* out) {
+  double d;
+  if (napi_get_value_double(env, v, &d) != napi_ok || d < 0) return 0;
+  *out = (uint64_t)d;
+  return 1;
+}
+
+static napi_value make_num(napi_env env, double d) {
+  napi_value v;
+  napi_create_double(env, d, &v);
+  return v;
+}
+
+static int prop_u32(napi_env env, napi_value obj, const char* name, uint32_t* out) {
+  napi_value v;
+  bool has = false;
+  if (napi_has_named_property(env, obj, name, &has) != napi_ok || !has) return 0;
+  if (napi_get_named_property(env, obj, name, &v) != napi_ok) return 0;
+  return get_u32(env, v, out);
+}
+static int prop_f64(napi_env env, napi_value obj, const char* name, double* out) {
+  napi_value v;
+  bool has = false;
+  if (napi_has_named_property(env, obj, name, &has) != napi_ok || !has) return 0;
+  if (napi_get_named_property(env, obj, name, &v) != napi_ok) return 0;
+  return get_f64(env, v, out);
+}
+
+/* typed array -> raw pointer; returns element count or -1.  null/undefined -> (NULL, 0). */
+static int64_t ta_data(napi_env env, napi_value v, napi_typedarray_type* type, void** data) {
+  napi_valuetype vt;
+  if (napi_typeof(env, v, &vt) != napi_ok) return -1;
+  if (vt == napi_null || vt == napi_undefined) {
+    *data = NULL;
+    return 0;
+  }
+  bool is_ta = false;
+  if (napi_is_typedarray(env, v, &is_ta) != napi_ok || !is_ta) return -1;
+  size_t len = 0, off = 0;
+  napi_value ab;
+  if (napi_get_typedarray_info(env, v, type, &len, data, &ab, &off) != napi_ok) return -1;
+  return (int64_t)len;
+}
+
+static napi_value new_typed(napi_env env, napi_typedarray_type type, size_t count, size_t elem, void** data) {
+  napi_value ab, ta;
+  if (napi_create_arraybuffer(env, count * elem, data, &ab) != napi_ok) return throw_msg(env, "allocation failed");
+  if (napi_create_typedarray(env, type, count, ab, 0, &ta) != napi_ok) return throw_msg(env, "allocation failed");
+  return ta;
+}
+
+/* ---- context handle ---------------------------------------------------------------------- */
+
+typedef struct {
+  sono_ctx* ctx;
+} handle_t;
+
+static void handle_finalize(napi_env env, void* data, void* hint) {
+  (void)env;
+  (void)hint;
+  handle_t* h = (handle_t*)data;
+  if (h->ctx) sono_destroy(h->ctx);
+  free(h);
+}
+
+static handle_t* get_handle(napi_env env, napi_value v) {
+  void* p = NULL;
+  if (napi_get_value_external(env, v, &p) != napi_ok || !p || !((handle_t*)p)->ctx) {
+    napi_throw_type_error(env, NULL, "not a live sonospec context");
+    return NULL;
+  }
+  return (handle_t*)p;
+}
+
+static napi_value throw_ctx(napi_env env, handle_t* h, int code) {
+  char buf[600];
+  snprintf(buf, sizeof buf, "%s (sonospec status %d)", sono_last_error(h->ctx), code);
+  napi_throw_error(env, NULL, buf);
+  return NULL;
+}
+
+/* create({fftN, hop, windowId, scaleMode, frameRule, twiddleMode, arith, outKind, inKind, binLo, binHi,
+ *         alpha, gainDB, rangeDB}, device) */
+static napi_value js_create(napi_env env, napi_callback_info info) {
+  ARGS(env, info, 1);
+  sono_config cfg;
+  memset(&cfg, 0, sizeof cfg);
+  cfg.fft_n = 1024;
+  cfg.hop = 256;
+  cfg.window_id = SONO_WIN_HANN;
+  cfg.gain_db = 20;
+  cfg.range_db = 80;
+  napi_value o = argv[0];
+  prop_u32(env, o, "fftN", &cfg.fft_n);
+  prop_u32(env, o, "hop", &cfg.hop);
+  prop_u32(env, o, "windowId", &cfg.window_id);
+  prop_u32(env, o, "scaleMode", &cfg.scale_mode);
+  prop_u32(env, o, "frameRule", &cfg.frame_rule);
+  prop_u32(env, o, "twiddleMode", &cfg.twiddle_mode);
+  prop_u32(env, o, "arith", &cfg.arith);
+  prop_u32(env, o, "outKind", &cfg.out_kind);
+  prop_u32(env, o, "inKind", &cfg.in_kind);
+  prop_u32(env, o, "binLo", &cfg.bin_lo);
+  prop_u32(env, o, "binHi", &cfg.bin_hi);
+  prop_f64(env, o, "alpha", &cfg.alpha);
+  prop_f64(env, o, "gainDB", &cfg.gain_db);
+  prop_f64(env, o, "rangeDB", &cfg.range_db);
+  uint32_t device = 0;
+  if (argc > 1) get_u32(env, argv[1], &device);
+  sono_ctx* c = sono_create((int)device, &cfg);
+  if (!c) return throw_msg(env, sono_create_error());
+  handle_t* h = (handle_t*)calloc(1, sizeof *h);
+  h->ctx = c;
+  napi_value ext;
+  if (napi_create_external(env, h, handle_finalize, NULL, &ext) != napi_ok) {
+    sono_destroy(c);
+    free(h);
+    return throw_msg(env, "napi_create_external failed");
+  }
+  return ext;
+}
+
+static napi_value js_destroy(napi_env env, napi_callback_info info) {
+  ARGS(env, info, 1);
+  void* p = NULL;
+  if (napi_get_value_external(env, argv[0], &p) == napi_ok && p) {
+    handle_t* h = (handle_t*)p;
+    if (h->ctx) sono_destroy(h->ctx);
+    h->ctx = NULL;
+  }
+  return NULL;
+}
+
+static napi_value js_device_count(napi_env env, napi_callback_info info) {
+  (void)info;
+  return make_num(env, sono_device_count());
+}
+
+static napi_value js_set_colormap(napi_env env, napi_callback_info info) {
+  ARGS(env, info, 2);
+  handle_t* h = get_handle(env, argv[0]);
+  if (!h) return NULL;
+  napi_typedarray_type t;
+  void* d;
+  int64_t n = ta_data(env, argv[1], &t, &d);
+  if (n < 0 || (d && (n != 1024 || (t != napi_uint8_array && t != napi_uint8_clamped_array))))
+    return throw_msg(env, "colour LUT must be a Uint8Array of 1024 bytes or null");
+  int rc = sono_set_colormap(h->ctx, (const uint8_t*)d);
+  return rc == SONO_OK ? NULL : throw_ctx(env, h, rc);
+}
+
+static napi_value js_set_tables(napi_env env, napi_callback_info info) {
+  ARGS(env, info, 4);
+  handle_t* h = get_handle(env, argv[0]);
+  if (!h) return NULL;
+  sono_config cfg;
+  sono_get_config(h->ctx, &cfg);
+  napi_typedarray_type t;
+  void *w, *c, *s;
+  int64_t nw = ta_data(env, argv[1], &t, &w);
+  if (nw < 0 || (w && (t != napi_float32_array || nw != (int64_t)cfg.fft_n))) return throw_msg(env, "window must be Float32Array(fftN)");
+  int64_t nc = ta_data(env, argv[2], &t, &c);
+  if (nc < 0 || (c && (t != napi_float64_array || nc != (int64_t)cfg.fft_n - 1))) return throw_msg(env, "twiddle cos must be Float64Array(fftN-1)");
+  int64_t ns = ta_data(env, argv[3], &t, &s);
+  if (ns < 0 || (s && (t != napi_float64_array || ns != (int64_t)cfg.fft_n - 1))) return throw_msg(env, "twiddle sin must be Float64Array(fftN-1)");
+  int rc = sono_set_tables(h->ctx, (const float*)w, (const double*)c, (const double*)s);
+  return rc == SONO_OK ? NULL : throw_ctx(env, h, rc);
+}
+
+static napi_value geometry_object(napi_env env, const sono_geometry* g) {
+  napi_value o;
+  napi_create_object(env, &o);
+  napi_set_named_property(env, o, "frames", make_num(env, (double)g->frames));
+  napi_set_named_property(env, o, "width", make_num(env, (double)g->width));
+  napi_set_named_property(env, o, "bins", make_num(env, (double)g->bins));
+  napi_set_named_property(env, o, "hop", make_num(env, (double)g->hop));
+  return o;
+}
+
+static napi_value js_geometry(napi_env env, napi_callback_info info) {
+  ARGS(env, info, 2);
+  handle_t* h = get_handle(env, argv[0]);
+  if (!h) return NULL;
+  uint64_t L;
+  if (!get_u64(env, argv[1], &L)) return throw_msg(env, "sample count expected");
+  sono_geometry g;
+  int rc = sono_geometry_of(h->ctx, L, &g);
+  if (rc != SONO_OK) return throw_ctx(env, h, rc);
+  return geometry_object(env, &g);
+}
+
+/* stft(handle, Float32Array | Int16Array) -> typed array of the context's out_kind */
+static napi_value js_stft(napi_env env, napi_callback_info info) {
+  ARGS(env, info, 2);
+  handle_t* h = get_handle(env, argv[0]);
+  if (!h) return NULL;
+  sono_config cfg;
+  sono_get_config(h->ctx, &cfg);
+  napi_typedarray_type t;
+  void* pcm;
+  int64_t n = ta_data(env, argv[1], &t, &pcm);
+  if (n < 0) return throw_msg(env, "PCM must be a typed array");
+  if (cfg.in_kind == SONO_IN_F32 && n > 0 && t != napi_float32_array) return throw_msg(env, "PCM must be a Float32Array");
+  if (cfg.in_kind == SONO_IN_I16 && n > 0 && t != napi_int16_array) return throw_msg(env, "PCM must be an Int16Array");
+  const uint64_t bytes = sono_out_bytes(h->ctx, (uint64_t)n);
+  void* out = NULL;
+  napi_value result;
+  if (cfg.out_kind == SONO_OUT_U8_INDEX)
+    result = new_typed(env, napi_uint8_array, (size_t)bytes, 1, &out);
+  else if (cfg.out_kind == SONO_OUT_RGBA8)
+    result = new_typed(env, napi_uint8_clamped_array, (size_t)bytes, 1, &out);
+  else
+    result = new_typed(env, napi_float32_array, (size_t)(bytes / 4), 4, &out);
+  if (!result) return NULL;
+  static uint8_t dummy_in[4], dummy_out[4];
+  int rc = sono_stft(h->ctx, pcm ? pcm : dummy_in, (uint64_t)n, bytes ? out : dummy_out, bytes ? bytes : 0, SONO_MEM_HOST);
+  if (rc != SONO_OK) return throw_ctx(env, h, rc);
+  return result;
+}
+
+static napi_value js_resample(napi_env env, napi_callback_info info) {
+  ARGS(env, info, 5);
+  handle_t* h = get_handle(env, argv[0]);
+  if (!h) return NULL;
+  napi_typedarray_type t;
+  void* in;
+  int64_t n = ta_data(env, argv[1], &t, &in);
+  uint64_t F, W;
+  uint32_t B;
+  if (n < 0 || !get_u64(env, argv[2], &F) || !get_u32(env, argv[3], &B) || !get_u64(env, argv[4], &W) || (uint64_t)n < F * B)
+    return throw_msg(env, "resample(handle, Uint8Array, frames, bins, outWidth)");
+  void* out;
+  napi_value result = new_typed(env, napi_uint8_array, (size_t)(W * B), 1, &out);
+  if (!result) return NULL;
+  if (W * B == 0) return result;
+  if (F == 0) {
+    memset(out, 0, (size_t)(W * B));
+    return result;
+  }
+  int rc = sono_resample(h->ctx, (const uint8_t*)in, F, B, W, (uint8_t*)out, SONO_MEM_HOST);
+  return rc == SONO_OK ? result : throw_ctx(env, h, rc);
+}
+
+static napi_value js_colorize(napi_env env, napi_callback_info info) {
+  ARGS(env, info, 6);
+  handle_t* h = get_handle(env, argv[0]);
+  if (!h) return NULL;
+  napi_typedarray_type t;
+  void* in;
+  int64_t n = ta_data(env, argv[1], &t, &in);
+  uint64_t W;
+  uint32_t B, row0, rows;
+  if (n < 0 || !get_u64(env, argv[2], &W) || !get_u32(env, argv[3], &B) || !get_u32(env, argv[4], &row0) ||
+      !get_u32(env, argv[5], &rows) || (uint64_t)n < W * B)
+    return throw_msg(env, "colorize(handle, Uint8Array, width, bins, row0, rows)");
+  void* out;
+  napi_value result = new_typed(env, napi_uint8_clamped_array, (size_t)(W * rows * 4), 1, &out);
+  if (!result) return NULL;
+  if (W * rows == 0) return result;
+  int rc = sono_colorize(h->ctx, (const uint8_t*)in, W, B, row0, rows, (uint8_t*)out, SONO_MEM_HOST);
+  return rc == SONO_OK ? result : throw_ctx(env, h, rc);
+}
+
+static napi_value js_frame_peaks(napi_env env, napi_callback_info info) {
+  ARGS(env, info, 4);
+  handle_t* h = get_handle(env, argv[0]);
+  if (!h) return NULL;
+  napi_typedarray_type t;
+  void* in;
+  int64_t n = ta_data(env, argv[1], &t, &in);
+  uint64_t F;
+  uint32_t B;
+  if (n < 0 || !get_u64(env, argv[2], &F) || !get_u32(env, argv[3], &B) || (uint64_t)n < F * B)
+    return throw_msg(env, "framePeaks(handle, Uint8Array, frames, bins)");
+  void *pb, *pv;
+  napi_value bins = new_typed(env, napi_int32_array, (size_t)F, 4, &pb);
+  napi_value vals = new_typed(env, napi_uint8_array, (size_t)F, 1, &pv);
+  if (!bins || !vals) return NULL;
+  if (F) {
+    int rc = sono_frame_peaks(h->ctx, (const uint8_t*)in, F, B, (int32_t*)pb, (uint8_t*)pv, SONO_MEM_HOST);
+    if (rc != SONO_OK) return throw_ctx(env, h, rc);
+  }
+  napi_value o;
+  napi_create_object(env, &o);
+  napi_set_named_property(env, o, "bins", bins);
+  napi_set_named_property(env, o, "values", vals);
+  return o;
+}
+
+/* ---- device-resident path (benchmarks, batch hosts): handles are opaque numbers ------------- */
+
+static napi_value js_device_malloc(napi_env env, napi_callback_info info) {
+  ARGS(env, info, 2);
+  handle_t* h = get_handle(env, argv[0]);
+  if (!h) return NULL;
+  uint64_t bytes;
+  if (!get_u64(env, argv[1], &bytes)) return throw_msg(env, "byte count expected");
+  void* p = sono_device_malloc(h->ctx, bytes);
+  if (!p) return throw_ctx(env, h, SONO_ERR_DEVICE);
+  napi_value v;
+  napi_create_bigint_uint64(env, (uint64_t)(uintptr_t)p, &v);
+  return v;
+}
+
+static int get_ptr(napi_env env, napi_value v, void** out) {
+  uint64_t u;
+  bool lossless;
+  if (napi_get_value_bigint_uint64(env, v, &u, &lossless) != napi_ok) return 0;
+  *out = (void*)(uintptr_t)u;
+  return 1;
+}
+
+static napi_value js_device_free(napi_env env, napi_callback_info info) {
+  ARGS(env, info, 2);
+  handle_t* h = get_handle(env, argv[0]);
+  void* p;
+  if (!h || !get_ptr(env, argv[1], &p)) return throw_msg(env, "deviceFree(handle, pointer)");
+  int rc = sono_device_free(h->ctx, p);
+  return rc == SONO_OK ? NULL : throw_ctx(env, h, rc);
+}
+
+static napi_value js_copy_to_device(napi_env env, napi_callback_info info) {
+  ARGS(env, info, 3);
+  handle_t* h = get_handle(env, argv[0]);
+  void* p;
+  if (!h || !get_ptr(env, argv[1], &p)) return throw_msg(env, "copyToDevice(handle, pointer, typedArray)");
+  napi_typedarray_type t;
+  void* src;
+  size_t len, off;
+  napi_value ab;
+  if (napi_get_typedarray_info(env, argv[2], &t, &len, &src, &ab, &off) != napi_ok) return throw_msg(env, "typed array expected");
+  static const size_t esz[] = {1, 1, 1, 2, 2, 4, 4, 4, 8, 8, 8};
+  int rc = sono_copy_to_device(h->ctx, p, src, (uint64_t)len * esz[t]);
+  return rc == SONO_OK ? NULL : throw_ctx(env, h, rc);
+}
+
+static napi_value js_copy_to_host(napi_env env, napi_callback_info info) {
+  ARGS(env, info, 3);
+  handle_t* h = get_handle(env, argv[0]);
+  void* p;
+  if (!h || !get_ptr(env, argv[2], &p)) return throw_msg(env, "copyToHost(handle, typedArray, pointer)");
+  napi_typedarray_type t;
+  void* dst;
+  size_t len, off;
+  napi_value ab;
+  if (napi_get_typedarray_info(env, argv[1], &t, &len, &dst, &ab, &off) != napi_ok) return throw_msg(env, "typed array expected");
+  static const size_t esz[] = {1, 1, 1, 2, 2, 4, 4, 4, 8, 8, 8};
+  int rc = sono_copy_to_host(h->ctx, dst, p, (uint64_t)len * esz[t]);
+  return rc == SONO_OK ? NULL : throw_ctx(env, h, rc);
+}
+
+static napi_value js_out_bytes(napi_env env, napi_callback_info info) {
+  ARGS(env, info, 2);
+  handle_t* h = get_handle(env, argv[0]);
+  uint64_t L;
+  if (!h || !get_u64(env, argv[1], &L)) return throw_msg(env, "outBytes(handle, samples)");
+  return make_num(env, (double)sono_out_bytes(h->ctx, L));
+}
+
+/* stftDevice(handle, pcmPtr, samples, outPtr, outCapacity, wait) */
+static napi_value js_stft_device(napi_env env, napi_callback_info info) {
+  ARGS(env, info, 5);
+  handle_t* h = get_handle(env, argv[0]);
+  void *in, *out;
+  uint64_t L, cap;
+  if (!h || !get_ptr(env, argv[1], &in) || !get_u64(env, argv[2], &L) || !get_ptr(env, argv[3], &out) || !get_u64(env, argv[4], &cap))
+    return throw_msg(env, "stftDevice(handle, pcmPtr, samples, outPtr, outCapacity[, wait])");
+  bool wait = true;
+  if (argc > 5) napi_get_value_bool(env, argv[5], &wait);
+  int rc = sono_stft_async(h->ctx, in, L, out, cap);
+  if (rc == SONO_OK && wait) rc = sono_wait(h->ctx);
+  return rc == SONO_OK ? NULL : throw_ctx(env, h, rc);
+}
+
+static napi_value js_wait(napi_env env, napi_callback_info info) {
+  ARGS(env, info, 1);
+  handle_t* h = get_handle(env, argv[0]);
+  if (!h) return NULL;
+  int rc = sono_wait(h->ctx);
+  return rc == SONO_OK ? NULL : throw_ctx(env, h, rc);
+}
+
+static napi_value js_timer_start(napi_env env, napi_callback_info info) {
+  ARGS(env, info, 1);
+  handle_t* h = get_handle(env, argv[0]);
+  if (!h) return NULL;
+  int rc = sono_timer_start(h->ctx);
+  return rc == SONO_OK ? NULL : throw_ctx(env, h, rc);
+}
+
+static napi_value js_timer_stop(napi_env env, napi_callback_info info) {
+  ARGS(env, info, 1);
+  handle_t* h = get_handle(env, argv[0]);
+  if (!h) return NULL;
+  return make_num(env, sono_timer_stop_ms(h->ctx));
+}
+
+/* ---- host rules ------------------------------------------------------------------------------ */
+
+static napi_value js_worker_hop(napi_env env, napi_callback_info info) {
+  ARGS(env, info, 2);
+  uint32_t n;
+  double pct;
+  if (!get_u32(env, argv[0], &n) || !get_f64(env, argv[1], &pct)) return throw_msg(env, "workerHop(fftN, overlapPercent)");
+  return make_num(env, sono_worker_hop(n, pct));
+}
+
+static napi_value js_plugin_noverlap(napi_env env, napi_callback_info info) {
+  ARGS(env, info, 4);
+  uint32_t n, ov, cw;
+  uint64_t L;
+  if (!get_u32(env, argv[0], &n) || !get_u32(env, argv[1], &ov) || !get_u64(env, argv[2], &L) || !get_u32(env, argv[3], &cw))
+    return throw_msg(env, "pluginNoverlap(fftN, noverlap, samples, canvasWidth)");
+  return make_num(env, sono_plugin_noverlap(n, ov, L, cw));
+}
+
+static napi_value js_overlap_from_percent(napi_env env, napi_callback_info info) {
+  ARGS(env, info, 2);
+  uint32_t n;
+  double pct;
+  if (!get_u32(env, argv[0], &n) || !get_f64(env, argv[1], &pct)) return throw_msg(env, "overlapFromPercent(fftN, percent)");
+  return make_num(env, sono_overlap_from_percent(n, pct));
+}
+
+static napi_value js_plugin_crop(napi_env env, napi_callback_info info) {
+  ARGS(env, info, 4);
+  uint32_t bins;
+  double sr, fmin, fmax;
+  if (!get_u32(env, argv[0], &bins) || !get_f64(env, argv[1], &sr) || !get_f64(env, argv[2], &fmin) || !get_f64(env, argv[3], &fmax))
+    return throw_msg(env, "pluginCrop(bins, sampleRate, fminHz, fmaxHz)");
+  int64_t sy, sh;
+  if (sono_plugin_crop(bins, sr, fmin, fmax, &sy, &sh) != SONO_OK) return throw_msg(env, "bad crop arguments");
+  napi_value o;
+  napi_create_object(env, &o);
+  napi_set_named_property(env, o, "sy", make_num(env, (double)sy));
+  napi_set_named_property(env, o, "sh", make_num(env, (double)sh));
+  return o;
+}
+
+static napi_value lut_common(napi_env env, napi_callback_info info, int worker) {
+  ARGS(env, info, 1);
+  napi_typedarray_type t;
+  void* cm;
+  int64_t n = ta_data(env, argv[0], &t, &cm);
+  if (n != 1024 || t != napi_float64_array) return throw_msg(env, "colour map must be a Float64Array of 256*4 values");
+  void* out;
+  napi_value result = new_typed(env, napi_uint8_array, 1024, 1, &out);
+  if (!result) return NULL;
+  if (worker)
+    sono_worker_lut((const double*)cm, (uint8_t*)out);
+  else
+    sono_plugin_lut((const double*)cm, (uint8_t*)out);
+  return result;
+}
+static napi_value js_plugin_lut(napi_env env, napi_callback_info info) { return lut_common(env, info, 0); }
+static napi_value js_worker_lut(napi_env env, napi_callback_info info) { return lut_common(env, info, 1); }
+
+static napi_value js_window_table(napi_env env, napi_callback_info info) {
+  ARGS(env, info, 3);
+  uint32_t id, n;
+  double alpha;
+  if (!get_u32(env, argv[0], &id) || !get_u32(env, argv[1], &n) || !get_f64(env, argv[2], &alpha))
+    return throw_msg(env, "windowTable(windowId, fftN, alpha)");
+  void* out;
+  napi_value result = new_typed(env, napi_float32_array, n, 4, &out);
+  if (!result) return NULL;
+  if (sono_window_table(id, n, alpha, (float*)out) != SONO_OK) return throw_msg(env, "No such window function");
+  return result;
+}
+
+static napi_value js_geometry_for(napi_env env, napi_callback_info info) {
+  ARGS(env, info, 4);
+  uint32_t n, hop, rule, lo = 0, hi = 0;
+  uint64_t L;
+  if (!get_u32(env, argv[0], &n) || !get_u32(env, argv[1], &hop) || !get_u32(env, argv[2], &rule) || !get_u64(env, argv[3], &L))
+    return throw_msg(env, "geometryFor(fftN, hop, frameRule, samples[, binLo, binHi])");
+  if (argc > 4) get_u32(env, argv[4], &lo);
+  if (argc > 5) get_u32(env, argv[5], &hi);
+  sono_geometry g;
+  if (sono_geometry_for(n, hop, rule, lo, hi, L, &g) != SONO_OK) return throw_msg(env, "bad geometry arguments");
+  return geometry_object(env, &g);
+}
+
+#define EXPORT(name, fn)                                                     \
+  do {                                                                       \
+    napi_value f_;                                                           \
+    if (napi_create_function(env, name, NAPI_AUTO_LENGTH, fn, NULL, &f_) != napi_ok) return NULL; \
+    if (napi_set_named_property(env, exports, name, f_) != napi_ok) return NULL;                  \
+  } while (0)
+
+static napi_value init(napi_env env, napi_value exports) {
+  EXPORT("deviceCount", js_device_count);
+  EXPORT("create", js_create);
+  EXPORT("destroy", js_destroy);
+  EXPORT("setColormap", js_set_colormap);
+  EXPORT("setTables", js_set_tables);
+  EXPORT("geometry", js_geometry);
+  EXPORT("outBytes", js_out_bytes);
+  EXPORT("stft", js_stft);
+  EXPORT("resample", js_resample);
+  EXPORT("colorize", js_colorize);
+  EXPORT("framePeaks", js_frame_peaks);
+  EXPORT("deviceMalloc", js_device_malloc);
+  EXPORT("deviceFree", js_device_free);
+  EXPORT("copyToDevice", js_copy_to_device);
+  EXPORT("copyToHost", js_copy_to_host);
+  EXPORT("stftDevice", js_stft_device);
+  EXPORT("wait", js_wait);
+  EXPORT("timerStart", js_timer_start);
+  EXPORT("timerStopMs", js_timer_stop);
+  EXPORT("workerHop", js_worker_hop);
+  EXPORT("pluginNoverlap", js_plugin_noverlap);
+  EXPORT("overlapFromPercent", js_overlap_from_percent);
+  EXPORT("pluginCrop", js_plugin_crop);
+  EXPORT("pluginLut", js_plugin_lut);
+  EXPORT("workerLut", js_worker_lut);
+  EXPORT("windowTable", js_window_table);
+  EXPORT("geometryFor", js_geometry_for);
+  napi_set_named_property(env, exports, "abiVersion", make_num(env, sono_abi_version()));
+  return exports;
+}
+
+NAPI_MODULE(NODE_GYP_MODULE_NAME, init)

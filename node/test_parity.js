@@ -1,0 +1,139 @@
+#!/usr/bin/env node
+'use strict';
+// Parity of the Node host side against the reference's golden outputs (tests/golden, produced by
+// tests/golden/gen_golden.js).  `node node/test_parity.js cpu` checks what needs no GPU (host rules,
+// option validation); without arguments it also renders on the GPU:
+//   exact mode  -> bit-identical RGBA / uint8 (tables computed by this V8, like the reference's)
+//   fast mode   -> colour indices within 1 LSB (cyclic at the plugin's 256 -> 0 wrap)
+const fs = require('fs');
+const path = require('path');
+const S = require('./index.js');
+const { Spectrogram, createSpectrogramPlugin, noverlapFromPercent } = require('./spectrogram_plugin.js');
+const { createInProcessWorker } = require('./spectrogram_worker.js');
+
+const G = path.join(__dirname, '..', 'tests', 'golden');
+const manifest = JSON.parse(fs.readFileSync(path.join(G, 'manifest.json'), 'utf8'));
+const cpuOnly = process.argv[2] === 'cpu';
+let checks = 0, failures = 0;
+function ok(cond, what) { checks++; if (!cond) { failures++; console.error('FAIL: ' + what); } }
+function load(name, Type) {
+  const b = fs.readFileSync(path.join(G, name));
+  return new Type(b.buffer.slice(b.byteOffset, b.byteOffset + b.byteLength));
+}
+function signal(name) { return load(manifest.signals[name].file, Float32Array); }
+function colormap(name) {
+  const f = load(manifest.colormaps[name], Float64Array), cm = [];
+  for (let i = 0; i < 256; i++) cm.push([f[4 * i], f[4 * i + 1], f[4 * i + 2], f[4 * i + 3]]);
+  return cm;
+}
+function equal(a, b) { if (a.length !== b.length) return false; for (let i = 0; i < a.length; i++) if (a[i] !== b[i]) return false; return true; }
+function maxCyclicDiff(a, b) { let m = 0; for (let i = 0; i < a.length; i++) { let d = (a[i] - b[i] + 256) % 256; d = Math.min(d, 256 - d); if (d > m) m = d; } return m; }
+function audioBuffer(x, sr) { return { sampleRate: sr, length: x.length, numberOfChannels: 1, getChannelData: () => x }; }
+const cases = (kind) => manifest.cases.filter((c) => c.kind === kind);
+
+// ---------------------------------------------------------------- host rules (no GPU)
+for (const r of cases('plugin_crop_grid')[0].rows) {
+  const c = S.native.pluginCrop(r.N / 2, r.sr, r.fmin, r.fmax);
+  ok(c.sy === r.sy && c.sh === r.sh, 'crop ' + JSON.stringify(r));
+}
+for (const c of cases('plugin_render')) {
+  if (c.colormap !== 'default' && c.colormap !== 'rainbow') continue;
+  const p = Spectrogram.create({ colorMap: colormap(c.colormap) });
+  ok(equal(p._colorMapUint, load(c.lut, Uint8Array)), 'plugin LUT ' + c.id);
+}
+for (const c of cases('plugin_get_frequencies')) {
+  const L = manifest.signals[c.signal].length;
+  const ov = S.native.pluginNoverlap(c.N, c.noverlap || 0, L, c.canvas_width);
+  const g = S.native.geometryFor(c.N, c.N - ov, S.FRAMES_PLUGIN_STRICT, L);
+  ok(g.frames === c.frames && g.bins === c.bins, 'plugin geometry ' + c.id);
+}
+for (const c of cases('worker_render')) {
+  const L = manifest.signals[c.signal].length, n = c.N || 1024;
+  const g = S.native.geometryFor(n, S.native.workerHop(n, c.overlap || 0), S.FRAMES_WORKER_COMPAT, L);
+  ok(g.width === c.width && g.bins === c.height, 'worker geometry ' + c.id);
+}
+{
+  const msgs = {};
+  for (const e of cases('plugin_errors')[0].errors) msgs[e.label] = e.message;
+  const expectThrow = (fn, msg, what) => { let got = null; try { fn(); } catch (e) { got = String(e.message || e); } ok(got === msg, what + ': ' + got); };
+  expectThrow(() => Spectrogram.create({ colorMap: Array.from({ length: 10 }, () => [0, 0, 0, 1]) }), msgs.short, 'short colormap');
+  expectThrow(() => Spectrogram.create({ colorMap: Array.from({ length: 256 }, () => [0, 0, 0]) }), msgs.bad_entry, 'bad entry');
+  expectThrow(() => Spectrogram.create({}), msgs.default_name, 'default name');
+  expectThrow(() => Spectrogram.create({ colorMap: 'viridis' }), msgs.unknown_name, 'unknown name');
+  expectThrow(() => S.windowId('kaiser'), cases('plugin_window_error')[0].message, 'unknown window');
+  const p = Spectrogram.create({ colorMap: 'gray' });
+  ok(p.fftSamples === 512 && p.height === 200 && p.noverlap === null && p.gainDB === 20 && p.rangeDB === 80 && p.scale === 'mel', 'defaults');
+  const q = createSpectrogramPlugin({ colorMap: colormap('default'), noverlap: 768 });
+  ok(q.frequencyMin === 10000 && q.frequencyMax === 128000 && q.scale === 'linear' && q.fftSamples === 1024 && q.height === 800, 'wsManager factory');
+  ok(noverlapFromPercent(1024, 75) === 768 && noverlapFromPercent(1024, null) === null, 'noverlap from percent');
+}
+// tables this V8 computes are the reference's (same engine family): bit-identical doubles
+for (const c of cases('worker_tables')) {
+  const tw = S.workerTwiddles(c.N);
+  ok(equal(tw.cos, load(c.twiddle_cos, Float64Array)) && equal(tw.sin, load(c.twiddle_sin, Float64Array)), 'worker twiddles ' + c.N);
+  ok(equal(S.workerHann(c.N), load(c.hann, Float32Array)), 'worker hann ' + c.N);
+}
+
+// ---------------------------------------------------------------- GPU
+if (!cpuOnly) {
+  if (S.native.deviceCount() < 1) { console.error('no GPU'); process.exit(2); }
+  for (const arith of ['exact', 'fast']) {
+    for (const c of cases('worker_render')) {
+      const w = createInProcessWorker({ arith });
+      let msg = null;
+      w.onmessage = (e) => { msg = e.data; };
+      const canvas = {};
+      w.postMessage({ type: 'init', canvas, options: c.colormap ? { colorMap: colormap(c.colormap) } : undefined });
+      const m = { type: 'render', buffer: signal(c.signal) };
+      if (c.N != null) m.fftSize = c.N;
+      if (c.overlap != null) m.overlap = c.overlap;
+      if (c.options) m.options = c.options;
+      w.postMessage(m);
+      const ref = load(c.rgba, Uint8Array);
+      ok(msg && msg.type === 'rendered' && msg.width === c.width && msg.height === c.height && canvas.width === c.width, 'worker msg ' + c.id);
+      if (arith === 'exact') ok(equal(msg.data, ref), 'worker exact ' + c.id);
+      else if (!c.colormap) ok(maxCyclicDiff(msg.data, ref) <= 1, 'worker fast ' + c.id);   // grey: channel value == index
+      w.terminate();
+    }
+    for (const c of cases('plugin_get_frequencies')) {
+      if (!c.frames) continue;
+      const opts = { fftSamples: c.N, windowFunc: c.window, colorMap: 'gray', scale: 'linear', arith, canvasWidth: c.canvas_width,
+                     gainDB: c.gainDB, rangeDB: c.rangeDB };
+      if (c.noverlap != null) opts.noverlap = c.noverlap;
+      if (c.alpha != null) opts.alpha = c.alpha;
+      const p = Spectrogram.create(opts);
+      const out = p.getFrequencies(audioBuffer(signal(c.signal), manifest.signals[c.signal].sample_rate))[0];
+      const ref = load(c.data, Uint8Array);
+      ok(out.length === c.frames && out[0].length === c.bins, 'plugin shape ' + c.id);
+      if (arith === 'exact') ok(equal(out.flat, ref), 'plugin exact ' + c.id);
+      else ok(maxCyclicDiff(out.flat, ref) <= 1, 'plugin fast ' + c.id);
+      p.destroy();
+    }
+  }
+  for (const c of cases('plugin_render')) {
+    const cm = (c.colormap === 'default' || c.colormap === 'rainbow') ? colormap(c.colormap) : c.colormap;
+    const p = Spectrogram.create({ fftSamples: c.N, noverlap: c.noverlap, colorMap: cm, scale: 'linear', frequencyMin: c.fmin,
+                                   frequencyMax: c.fmax, windowFunc: c.window, arith: 'exact', canvasWidth: c.out_width });
+    const img = p.render(audioBuffer(signal(c.signal), manifest.signals[c.signal].sample_rate), c.out_width);
+    ok(img.width === c.image_width && img.height === c.image_height && equal(img.data, load(c.rgba, Uint8Array)), 'plugin render ' + c.id);
+    ok(img.crop.sy === c.crop.sy && img.crop.sh === c.crop.sh, 'plugin crop ' + c.id);
+    p.destroy();
+  }
+  // render before init is dropped; setOptions installs the colour map
+  {
+    const c = cases('worker_contract')[0];
+    const w = createInProcessWorker({ arith: 'exact' });
+    const got = [];
+    w.onmessage = (e) => got.push(e.data);
+    w.postMessage({ type: 'render', buffer: signal(c.signal), fftSize: 1024, overlap: 75 });
+    ok(got.length === 0, 'render before init dropped');
+    w.postMessage({ type: 'init', canvas: {} });
+    w.postMessage({ type: 'setOptions', options: { colorMap: colormap('rainbow') } });
+    w.postMessage({ type: 'render', buffer: signal(c.signal), fftSize: 1024, overlap: 75 });
+    ok(got.length === 1 && equal(got[0].data, load(c.rgba, Uint8Array)), 'worker contract');
+    w.terminate();
+  }
+}
+
+console.log(JSON.stringify({ checks, failures, gpu: !cpuOnly }));
+process.exit(failures ? 1 : 0);
