@@ -88,8 +88,34 @@ typedef enum sono_out_kind {
   SONO_OUT_RGBA8 = 1,    /* [row][column] RGBA8, row 0 = highest bin, column = frame
                             (ImageData layout of the worker and of drawSpectrogram)              */
   SONO_OUT_F32_DB = 2,   /* [frame][bin] float32 20*log10(m), m = |X| (worker) or 2/N*|X| (plugin) */
-  SONO_OUT_F32_MAG = 3   /* [frame][bin] float32 m                                               */
+  SONO_OUT_F32_MAG = 3,  /* [frame][bin] float32 m                                               */
+  SONO_OUT_FEATURES = 4  /* [frame] sono_frame_feature: spectral peak of each frame over the kept band */
 } sono_out_kind;
+
+/* Per-frame spectral feature (SONO_OUT_FEATURES).  peak_bin is the first bin (absolute index, DC = 0)
+ * of [bin_lo, bin_hi) whose float32 magnitude is strictly greater than all earlier ones -- the
+ * strict-> running-maximum rule of the plugin's FFT, spectrogram.esm.js:196, applied per frame;
+ * peak_idx is that bin's colour index under the context's quantiser.  The reference derives no
+ * spectral feature itself (its auto-ID panel reads user-placed markers, autoIdPanel.js:1388-1468);
+ * these records are what a batch host turns into the kHz / ms fields autoIdHK expects. */
+typedef struct sono_frame_feature {
+  int32_t peak_bin;
+  uint8_t peak_idx;
+  uint8_t reserved[3];
+} sono_frame_feature;
+
+/* One detected call: a maximal run of frames whose peak_idx >= threshold (sono_segment_calls). */
+typedef struct sono_call {
+  uint64_t start_frame; /* first frame of the run                                  */
+  uint64_t end_frame;   /* last frame of the run (inclusive)                       */
+  uint64_t peak_frame;  /* frame with the largest peak_idx (first one wins)        */
+  int32_t start_bin;    /* peak_bin at start_frame                                 */
+  int32_t end_bin;      /* peak_bin at end_frame                                   */
+  int32_t high_bin;     /* largest peak_bin in the run                             */
+  int32_t low_bin;      /* smallest peak_bin in the run                            */
+  int32_t peak_bin;     /* peak_bin at peak_frame                                  */
+  uint32_t peak_idx;    /* peak_idx at peak_frame                                  */
+} sono_call;
 
 typedef enum sono_in_kind {
   SONO_IN_F32 = 0, /* float32 samples in [-1,1]                       */
@@ -148,6 +174,13 @@ int sono_plugin_crop(uint32_t bins, double sample_rate, double fmin_hz, double f
  * rule spectrogramWorker.js:128-143 (NaN channel = absent). */
 int sono_plugin_lut(const double* colormap_rgba, uint8_t* lut_rgba);
 int sono_worker_lut(const double* colormap_rgba, uint8_t* lut_rgba);
+/* Call segmentation over per-frame features (host, O(frames)): maximal runs of frames with
+ * peak_idx >= threshold that are at least min_frames long.  `first_frame` is added to the frame
+ * numbers (for chunks of a longer recording).  Returns the number of calls found; at most
+ * `capacity` are written.  A run touching the last frame is reported like any other: a host that
+ * splits one recording into chunks merges it with a run starting at frame 0 of the next chunk. */
+int64_t sono_segment_calls(const sono_frame_feature* features, uint64_t frames, uint32_t threshold, uint32_t min_frames,
+                           uint64_t first_frame, sono_call* out, uint64_t capacity);
 /* Window table exactly as the reference fills it (float32).  SONO_ERR_WINDOW for an unknown id. */
 int sono_window_table(uint32_t window_id, uint32_t fft_n, double alpha, float* out);
 /* Twiddle table in the flat stage layout: the stage with half size T occupies [T-1, 2T-1). */

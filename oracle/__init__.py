@@ -70,6 +70,8 @@ def lib():
         L.orc_worker_render.argtypes = [f32p, C.c_size_t, C.c_int, C.c_double, u8p, f64p, f64p, u8p, u8p]
         L.orc_worker_render_mt.argtypes = [f32p, C.c_size_t, C.c_int, C.c_double, u8p, u8p, C.c_int]
         L.orc_frame_peaks.argtypes = [u8p, C.c_size_t, C.c_int, C.c_int, C.c_int, i32p, u8p]
+        L.orc_worker_magnitudes.argtypes = [f32p, C.c_size_t, C.c_int, C.c_int, C.c_size_t, f32p, u8p]
+        L.orc_frame_peaks_f32.argtypes = [f32p, C.c_size_t, C.c_int, C.c_int, C.c_int, i32p]
         _lib = L
     return _lib
 
@@ -236,3 +238,21 @@ def frame_peaks(idx, lo=0, hi=None):
     pb, pv = np.empty(F, np.int32), np.empty(F, np.uint8)
     lib().orc_frame_peaks(_p(idx, C.c_uint8), F, B, lo, hi, _p(pb, C.c_int32), _p(pv, C.c_uint8))
     return pb, pv
+
+
+def worker_magnitudes(x, n, hop, frames):
+    """float32 |X| and colour index of every worker frame x bin."""
+    x = _f32(x)
+    mag = np.empty((frames, n // 2), np.float32)
+    idx = np.empty((frames, n // 2), np.uint8)
+    lib().orc_worker_magnitudes(_p(x, C.c_float), x.shape[0], n, hop, frames, _p(mag, C.c_float), _p(idx, C.c_uint8))
+    return mag, idx
+
+
+def frame_peaks_f32(mag, lo=0, hi=None):
+    mag = np.ascontiguousarray(mag, np.float32)
+    F, B = mag.shape
+    hi = B if hi is None else hi
+    pb = np.empty(F, np.int32)
+    lib().orc_frame_peaks_f32(_p(mag, C.c_float), F, B, lo, hi, _p(pb, C.c_int32))
+    return pb

@@ -472,7 +472,46 @@ void orc_worker_render_mt(const float *x, size_t length, int n, double overlap_p
   worker_render_impl(x, length, n, overlap_pct, lut, NULL, NULL, rgba, NULL, threads);
 }
 
+void orc_worker_magnitudes(const float *x, size_t length, int n, int hop, size_t frames, float *mag_out,
+                           uint8_t *idx_out) {
+  (void)length;
+  float *re = (float *)malloc(sizeof(float) * (size_t)n), *im = (float *)malloc(sizeof(float) * (size_t)n);
+  float *win = (float *)malloc(sizeof(float) * (size_t)n);
+  double *ct = (double *)malloc(sizeof(double) * (size_t)n), *st = (double *)malloc(sizeof(double) * (size_t)n);
+  orc_worker_hann(n, win);
+  orc_worker_twiddles(n, ct, st);
+  const size_t H = (size_t)n / 2;
+  for (size_t f = 0; f < frames; f++) {
+    const float *sig = x + f * (size_t)hop;
+    for (int j = 0; j < n; j++) {
+      re[j] = (float)((double)sig[j] * (double)win[j]);
+      im[j] = 0.0f;
+    }
+    orc_worker_fft(re, im, n, ct, st);
+    for (size_t y = 0; y < H; y++) {
+      const double e = re[y], s = im[y];
+      if (mag_out) mag_out[f * H + y] = (float)sqrt(e * e + s * s);
+      if (idx_out) idx_out[f * H + y] = worker_index(re[y], im[y]);
+    }
+  }
+  free(re); free(im); free(win); free(ct); free(st);
+}
+
 /* ---- per-frame features ------------------------------------------------------------------- */
+
+void orc_frame_peaks_f32(const float *mag, size_t frames, int bins, int lo, int hi, int32_t *peak_bin) {
+  for (size_t f = 0; f < frames; f++) {
+    const float *row = mag + f * (size_t)bins;
+    float best = -1.0f;
+    int bk = lo;
+    for (int k = lo; k < hi; k++)
+      if (row[k] > best) {
+        best = row[k];
+        bk = k;
+      }
+    peak_bin[f] = bk;
+  }
+}
 
 void orc_frame_peaks(const uint8_t *idx, size_t frames, int bins, int lo, int hi, int32_t *peak_bin,
                      uint8_t *peak_idx) {

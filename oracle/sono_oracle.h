@@ -126,7 +126,17 @@ void orc_worker_render(const float *x, size_t length, int n, double overlap_pct,
 void orc_worker_render_mt(const float *x, size_t length, int n, double overlap_pct,
                           const uint8_t *lut, uint8_t *rgba, int threads);
 
+/* Worker magnitudes: float32(sqrt(re^2+im^2)) of every frame x bin (spectrogramWorker.js:71-72,
+ * rounded to float32 for the feature definition below), and the colour index beside it. */
+void orc_worker_magnitudes(const float *x, size_t length, int n, int hop, size_t frames, float *mag_out,
+                           uint8_t *idx_out);
+
 /* ---- per-frame features (build-defined; strict-> first-wins rule of :196) ------------ */
+
+/* For every frame of a frames x bins float32 magnitude matrix: the first bin in [bin_lo, bin_hi)
+ * whose magnitude is strictly greater than all earlier ones (no reference counterpart: the
+ * reference computes no per-frame feature, so this restates the engine's own definition). */
+void orc_frame_peaks_f32(const float *mag, size_t frames, int bins, int bin_lo, int bin_hi, int32_t *peak_bin);
 
 /* For every frame of a frames x bins uint8 index matrix: the first bin in [bin_lo, bin_hi)
  * holding the maximum index, and that maximum. */

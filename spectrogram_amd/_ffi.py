@@ -23,7 +23,7 @@ SCALE_WORKER_LOG5, SCALE_PLUGIN_DB = 0, 1
 FRAMES_PLUGIN_STRICT, FRAMES_WORKER_COMPAT = 0, 1
 TW_ACCURATE, TW_PLUGIN_RECURRENCE, TW_HOST_TABLE = 0, 1, 2
 ARITH_FAST_F32, ARITH_EXACT_F64 = 0, 1
-OUT_U8_INDEX, OUT_RGBA8, OUT_F32_DB, OUT_F32_MAG = 0, 1, 2, 3
+OUT_U8_INDEX, OUT_RGBA8, OUT_F32_DB, OUT_F32_MAG, OUT_FEATURES = 0, 1, 2, 3, 4
 IN_F32, IN_I16 = 0, 1
 MEM_HOST, MEM_DEVICE = 0, 1
 
@@ -35,6 +35,12 @@ class SonoConfig(C.Structure):
         ("in_kind", C.c_uint32), ("bin_lo", C.c_uint32), ("bin_hi", C.c_uint32), ("reserved0", C.c_uint32),
         ("alpha", C.c_double), ("gain_db", C.c_double), ("range_db", C.c_double), ("reserved", C.c_uint32 * 4),
     ]
+
+
+FEATURE_DTYPE = np.dtype([("peak_bin", np.int32), ("peak_idx", np.uint8), ("reserved", np.uint8, (3,))])
+CALL_DTYPE = np.dtype([("start_frame", np.uint64), ("end_frame", np.uint64), ("peak_frame", np.uint64),
+                       ("start_bin", np.int32), ("end_bin", np.int32), ("high_bin", np.int32), ("low_bin", np.int32),
+                       ("peak_bin", np.int32), ("peak_idx", np.uint32)])
 
 
 class SonoGeometry(C.Structure):
@@ -55,6 +61,7 @@ SYMBOLS = {
                                    C.POINTER(C.c_int64)]),
     "sono_plugin_lut": (C.c_int, [_VP, _VP]),
     "sono_worker_lut": (C.c_int, [_VP, _VP]),
+    "sono_segment_calls": (C.c_int64, [_VP, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint64, _VP, C.c_uint64]),
     "sono_window_table": (C.c_int, [C.c_uint32, C.c_uint32, C.c_double, _VP]),
     "sono_twiddle_table": (C.c_int, [C.c_uint32, C.c_uint32, _VP, _VP]),
     "sono_create": (_VP, [C.c_int, C.POINTER(SonoConfig)]),

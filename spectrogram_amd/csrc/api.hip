@@ -130,7 +130,7 @@ sono_ctx* sono_create(int device, const sono_config* cfg) {
     return nullptr;
   }
   if (cfg->scale_mode > SONO_SCALE_PLUGIN_DB || cfg->frame_rule > SONO_FRAMES_WORKER_COMPAT ||
-      cfg->twiddle_mode > SONO_TW_HOST_TABLE || cfg->arith > SONO_ARITH_EXACT_F64 || cfg->out_kind > SONO_OUT_F32_MAG ||
+      cfg->twiddle_mode > SONO_TW_HOST_TABLE || cfg->arith > SONO_ARITH_EXACT_F64 || cfg->out_kind > SONO_OUT_FEATURES ||
       cfg->in_kind > SONO_IN_I16) {
     fail(nullptr, SONO_ERR_ARG, "config enum out of range");
     return nullptr;
@@ -265,6 +265,7 @@ uint64_t sono_out_bytes(const sono_ctx* c, uint64_t L) {
   switch (c->cfg.out_kind) {
     case SONO_OUT_U8_INDEX: return g.frames * g.bins;
     case SONO_OUT_RGBA8: return g.width * g.bins * 4;
+    case SONO_OUT_FEATURES: return g.frames * sizeof(sono_frame_feature);
     default: return g.frames * g.bins * 4;
   }
 }

@@ -203,6 +203,44 @@ int sono_worker_lut(const double* cm, uint8_t* lut) {  // spectrogramWorker.js:1
   return SONO_OK;
 }
 
+int64_t sono_segment_calls(const sono_frame_feature* f, uint64_t frames, uint32_t thr, uint32_t min_frames,
+                           uint64_t first_frame, sono_call* out, uint64_t cap) {
+  if (!f && frames) return SONO_ERR_ARG;
+  if (min_frames == 0) min_frames = 1;
+  int64_t found = 0;
+  uint64_t i = 0;
+  while (i < frames) {
+    if (f[i].peak_idx < thr) {
+      i++;
+      continue;
+    }
+    uint64_t j = i;
+    sono_call c;
+    c.start_frame = first_frame + i;
+    c.start_bin = c.high_bin = c.low_bin = c.peak_bin = f[i].peak_bin;
+    c.peak_idx = f[i].peak_idx;
+    c.peak_frame = first_frame + i;
+    while (j < frames && f[j].peak_idx >= thr) {
+      if (f[j].peak_bin > c.high_bin) c.high_bin = f[j].peak_bin;
+      if (f[j].peak_bin < c.low_bin) c.low_bin = f[j].peak_bin;
+      if (f[j].peak_idx > c.peak_idx) {  // strict: the first frame holding the maximum wins
+        c.peak_idx = f[j].peak_idx;
+        c.peak_bin = f[j].peak_bin;
+        c.peak_frame = first_frame + j;
+      }
+      j++;
+    }
+    c.end_frame = first_frame + j - 1;
+    c.end_bin = f[j - 1].peak_bin;
+    if (j - i >= min_frames) {
+      if (out && (uint64_t)found < cap) out[found] = c;
+      found++;
+    }
+    i = j;
+  }
+  return found;
+}
+
 int sono_window_table(uint32_t id, uint32_t n, double alpha, float* out) {
   if (!out || n < 2) return SONO_ERR_ARG;
   return fill_window(id, n, alpha, out);

@@ -93,6 +93,61 @@ __global__ __launch_bounds__(kThreads) void stft_general_kernel(StftParams p, Fa
       }
     }
     __syncthreads();
+    if (p.out_kind == SONO_OUT_FEATURES) {
+      // per-frame peak: first bin whose float32 magnitude exceeds all earlier ones (strict >)
+      float best_m = -1.0f;
+      uint32_t best_k = p.bin_lo;
+      for (uint32_t y = p.bin_lo + tid; y < p.bin_hi; y += kThreads) {
+        const float r = re[y], i = im[y];
+        float m;
+        if constexpr (sizeof(A) == 8) {
+          const double e = r, s = i;
+          const double mag = sqrt(e * e + s * s);
+          m = (p.scale_mode == SONO_SCALE_WORKER_LOG5) ? (float)mag : (float)(two_over_n * mag);
+        } else {
+          m = sqrtf(r * r + i * i);
+        }
+        if (m > best_m) {
+          best_m = m;
+          best_k = y;
+        }
+      }
+      __shared__ float red_m[kThreads];
+      __shared__ uint32_t red_k[kThreads];
+      red_m[tid] = best_m;
+      red_k[tid] = best_k;
+      __syncthreads();
+      for (uint32_t s = kThreads / 2; s > 0; s >>= 1) {
+        if (tid < s) {
+          const float om = red_m[tid + s];
+          const uint32_t ok = red_k[tid + s];
+          if (om > red_m[tid] || (om == red_m[tid] && ok < red_k[tid])) {
+            red_m[tid] = om;
+            red_k[tid] = ok;
+          }
+        }
+        __syncthreads();
+      }
+      if (tid == 0) {
+        const uint32_t k = red_k[0];
+        const float r = re[k], i = im[k];
+        uint32_t idx;
+        if constexpr (sizeof(A) == 8) {
+          idx = (p.scale_mode == SONO_SCALE_WORKER_LOG5)
+                    ? worker_index_exact(r, i)
+                    : plugin_index_exact(plugin_mag_exact(r, i, two_over_n), p.gain_db, p.range_db);
+        } else {
+          idx = fast_index(r * r + i * i, fs);
+        }
+        sono_frame_feature ft;
+        ft.peak_bin = (int32_t)k;
+        ft.peak_idx = (uint8_t)idx;
+        ft.reserved[0] = ft.reserved[1] = ft.reserved[2] = 0;
+        reinterpret_cast<sono_frame_feature*>(p.out)[p.col0 + first + fl] = ft;
+      }
+      __syncthreads();
+      continue;
+    }
     for (uint32_t y = p.bin_lo + tid; y < p.bin_hi; y += kThreads) {
       const float r = re[y], i = im[y];
       if (p.out_kind == SONO_OUT_U8_INDEX || p.out_kind == SONO_OUT_RGBA8) {

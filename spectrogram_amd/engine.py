@@ -98,6 +98,8 @@ class Engine:
             return np.empty((g.frames, g.bins), np.uint8)
         if k == F.OUT_RGBA8:
             return np.empty((g.bins, g.width, 4), np.uint8)
+        if k == F.OUT_FEATURES:
+            return np.empty(g.frames, F.FEATURE_DTYPE)
         return np.empty((g.frames, g.bins), np.float32)
 
     def _in_array(self, pcm):
@@ -197,6 +199,16 @@ def worker_lut(colormap):
     lut = np.empty(1024, np.uint8)
     F.lib().sono_worker_lut(F.ptr(cm), F.ptr(lut))
     return lut
+
+
+def segment_calls(features, threshold, min_frames=1, first_frame=0):
+    """Maximal runs of frames with peak_idx >= threshold (host side of the feature pass)."""
+    f = np.ascontiguousarray(features, F.FEATURE_DTYPE)
+    n = int(F.lib().sono_segment_calls(F.ptr(f), len(f), int(threshold), int(min_frames), int(first_frame), None, 0))
+    out = np.zeros(max(n, 0), F.CALL_DTYPE)
+    if n > 0:
+        F.lib().sono_segment_calls(F.ptr(f), len(f), int(threshold), int(min_frames), int(first_frame), F.ptr(out), n)
+    return out
 
 
 def window_table(window_id_, fft_n, alpha=0.0):

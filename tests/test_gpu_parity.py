@@ -323,3 +323,56 @@ def test_full_size_periodic_property():
     # accurate twiddles vs the plugin's recurrence at N=1024 differ by up to ~0.13 dB: allow 1 LSB
     d = cyc_diff(head, ref)
     assert d.max() <= 1
+
+
+# ------------------------------------------------------------------ per-frame features (SONO_OUT_FEATURES)
+def test_features_exact_bit_exact_against_checker():
+    """Integer feature indices are bit-exact: peak_bin is the strict-> first-wins argmax of the float32
+    magnitudes (which the exact arithmetic reproduces bit for bit), peak_idx that bin's colour index."""
+    x = G.signal("bat")
+    # plugin semantics, full band and a cropped band
+    idx, mags, _, _ = oracle.plugin_get_frequencies(x, 1024, 768, want_mags=True)
+    for lo, hi in ((0, 0), (40, 320)):
+        with plugin_engine(1024, 256, F.ARITH_EXACT_F64, out_kind=F.OUT_FEATURES, bin_lo=lo, bin_hi=hi) as eng:
+            ft = eng.stft(x)
+        ref = oracle.frame_peaks_f32(mags, lo, hi or 512)
+        assert np.array_equal(ft["peak_bin"], ref)
+        assert np.array_equal(ft["peak_idx"], idx[np.arange(len(ref)), ref])
+    # worker semantics
+    hop = E.worker_hop(1024, 75)
+    _, width, frames = oracle.worker_geometry(len(x), 1024, 75)
+    wm, wi = oracle.worker_magnitudes(x, 1024, hop, frames)
+    with worker_engine(1024, hop, F.ARITH_EXACT_F64, out_kind=F.OUT_FEATURES) as eng:
+        ft = eng.stft(x)
+    ref = oracle.frame_peaks_f32(wm)
+    assert len(ft) == frames == width + 1
+    assert np.array_equal(ft["peak_bin"], ref) and np.array_equal(ft["peak_idx"], wi[np.arange(frames), ref])
+
+
+def test_features_fast_agree_unless_the_two_top_bins_tie():
+    x = G.signal("bat")
+    _, mags, _, _ = oracle.plugin_get_frequencies(x, 1024, 768, want_mags=True)
+    ref = oracle.frame_peaks_f32(mags)
+    with plugin_engine(1024, 256, F.ARITH_FAST_F32, out_kind=F.OUT_FEATURES) as eng:
+        ft = eng.stft(x)
+    diff = np.nonzero(ft["peak_bin"] != ref)[0]
+    for f in diff:                                   # only near-ties may move (float32 vs the reference's arithmetic)
+        a, b = mags[f, ref[f]], mags[f, ft["peak_bin"][f]]
+        assert abs(a - b) <= 2e-5 * a
+    assert len(diff) <= 1
+
+
+def test_feature_pass_to_autoid_data():
+    """bat-like signal: 5 ms down-sweeping pulses every 20 ms -> calls with falling frequency whose
+    measured fields are valid matcher input."""
+    from spectrogram_amd.autoid import auto_id_hk, call_to_autoid_data
+    x, sr = G.signal("bat"), 384000
+    with plugin_engine(1024, 256, F.ARITH_FAST_F32, out_kind=F.OUT_FEATURES, bin_lo=40, bin_hi=280) as eng:
+        ft = eng.stft(x)
+    calls = E.segment_calls(ft, threshold=150, min_frames=3)
+    assert 1 <= len(calls) <= 3
+    for c in calls:
+        d = call_to_autoid_data(c, 1024, 256, sr, call_type="FM")
+        assert d["startFreq"] > d["endFreq"] and 30 <= d["lowestFreq"] < d["highestFreq"] <= 90
+        assert 2.0 <= d["duration"] <= 8.0
+        assert isinstance(auto_id_hk(d, G.manifest["species_rules"]), str)
