@@ -74,6 +74,25 @@ for (const c of cases('worker_tables')) {
   ok(equal(S.workerHann(c.N), load(c.hann, Float32Array)), 'worker hann ' + c.N);
 }
 
+// matcher semantics over the reference's own rule table and verdicts
+{
+  const { autoIdHK, segmentCalls, callToAutoIdData } = require('./autoid.js');
+  let bad = 0;
+  for (const v of manifest.autoid_verdicts) {
+    const d = {};
+    for (const k of Object.keys(v.data)) d[k] = v.data[k] === 'NaN' ? NaN : v.data[k];
+    if (autoIdHK(d, manifest.species_rules) !== v.result) bad++;
+  }
+  ok(bad === 0 && manifest.autoid_verdicts.length > 700, 'autoIdHK verdicts, mismatches: ' + bad);
+  const idx = new Uint8Array(40), bin = new Int32Array(40).fill(100);
+  idx.set([90, 120, 200, 200, 150, 110, 95], 5); bin.set([213, 200, 180, 170, 160, 150, 147], 5);
+  const calls = segmentCalls({ peakBin: bin, peakIdx: idx }, 80, 2, 1000);
+  ok(calls.length === 1 && calls[0].startFrame === 1005 && calls[0].endFrame === 1011 && calls[0].peakFrame === 1007 &&
+     calls[0].peakBin === 180 && calls[0].highBin === 213 && calls[0].lowBin === 147, 'segmentCalls');
+  const d = callToAutoIdData(calls[0], 1024, 256, 384000, { callType: 'FM' });
+  ok(Math.abs(d.duration - 7 * 256 / 384) < 1e-9 && Math.abs(d.bandwidth - 66 * 0.375) < 1e-9, 'callToAutoIdData');
+}
+
 // ---------------------------------------------------------------- GPU
 if (!cpuOnly) {
   if (S.native.deviceCount() < 1) { console.error('no GPU'); process.exit(2); }

@@ -1,0 +1,93 @@
+"""Spreading the hot path over the GPUs of one node: no collective in the data path.
+
+Recordings are independent, and so are the frames of one recording, so multi-GPU operation is pure
+partitioning plus a host-side gather:
+
+* many files (the reference loads one file at a time, modules/fileLoader.js:110-157): each rank takes
+  whole files, balanced by size (`assign_files`);
+* one long recording: contiguous spans of frames, each span reading `fft_n - hop` samples past its
+  last hop so that every frame is computed exactly once (`split_recording`); a call that touches the
+  last frame of a span is merged with one starting at the first frame of the next (`merge_calls`).
+
+`gather_results` collects per-rank results on rank 0 with torch.distributed's object gather (any
+backend; gloo on CPU, RCCL on GPU) -- the only communication there is.
+"""
+from . import _ffi as F
+from . import engine as E
+
+
+def assign_files(sizes, world_size):
+    """Longest-processing-time-first assignment of files to ranks.  Returns, per rank, the list of
+    file indices (each ascending); deterministic for equal sizes."""
+    order = sorted(range(len(sizes)), key=lambda i: (-int(sizes[i]), i))
+    load = [0] * world_size
+    out = [[] for _ in range(world_size)]
+    for i in order:
+        r = min(range(world_size), key=lambda k: (load[k], k))
+        out[r].append(i)
+        load[r] += int(sizes[i])
+    return [sorted(v) for v in out]
+
+
+def split_recording(n_samples, fft_n, hop, world_size, frame_rule=F.FRAMES_PLUGIN_STRICT, align=64):
+    """Contiguous frame spans of one recording, one per rank.
+
+    Returns a list of dicts {rank, first_frame, frames, sample_start, sample_count}.  Span k covers
+    frames [first_frame, first_frame + frames); it needs samples [first_frame*hop, (last_frame)*hop + fft_n)
+    -- i.e. fft_n - hop samples of halo past its last hop.  Under SONO_FRAMES_PLUGIN_STRICT a frame
+    exists only if one more sample follows it, so `sample_count` includes that sample for the last
+    frame of the recording.  Span boundaries are multiples of `align` frames (image columns of one
+    span then start on aligned addresses)."""
+    g = E.geometry_for(fft_n, hop, frame_rule, n_samples)
+    total = int(g.frames)
+    per = -(-total // world_size)
+    per = -(-per // align) * align
+    spans = []
+    for r in range(world_size):
+        f0 = min(total, r * per)
+        f1 = min(total, (r + 1) * per)
+        n = f1 - f0
+        if n > 0:
+            s0 = f0 * hop
+            s1 = (f1 - 1) * hop + fft_n
+            if frame_rule == F.FRAMES_PLUGIN_STRICT:
+                s1 += 1                      # a + N < L must hold for the span's last frame too
+            s1 = min(s1, n_samples)
+            spans.append(dict(rank=r, first_frame=f0, frames=n, sample_start=s0, sample_count=s1 - s0))
+        else:
+            spans.append(dict(rank=r, first_frame=f0, frames=0, sample_start=0, sample_count=0))
+    return spans
+
+
+def merge_calls(call_lists):
+    """Concatenate per-span call records (absolute frame numbers, spans in order) and stitch a run that
+    ends on the last frame of one span to a run that starts on the first frame of the next."""
+    import numpy as np
+    merged = []
+    for calls in call_lists:
+        for c in calls:
+            c = c.copy()
+            if merged and int(merged[-1]["end_frame"]) + 1 == int(c["start_frame"]):
+                p = merged[-1]
+                p["end_frame"] = c["end_frame"]
+                p["end_bin"] = c["end_bin"]
+                p["high_bin"] = max(int(p["high_bin"]), int(c["high_bin"]))
+                p["low_bin"] = min(int(p["low_bin"]), int(c["low_bin"]))
+                if int(c["peak_idx"]) > int(p["peak_idx"]):
+                    p["peak_idx"], p["peak_bin"], p["peak_frame"] = c["peak_idx"], c["peak_bin"], c["peak_frame"]
+            else:
+                merged.append(c)
+    out = np.zeros(len(merged), F.CALL_DTYPE)
+    for i, c in enumerate(merged):
+        out[i] = c
+    return out
+
+
+def gather_results(local, dst=0):
+    """Host-side gather of arbitrary per-rank results on rank `dst` (list indexed by rank, else None)."""
+    import torch.distributed as dist
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return [local]
+    out = [None] * dist.get_world_size() if dist.get_rank() == dst else None
+    dist.gather_object(local, out, dst=dst)
+    return out
