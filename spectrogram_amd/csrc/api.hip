@@ -4,6 +4,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -304,6 +305,7 @@ int sono_stft_async(sono_ctx* c, const void* pcm, uint64_t L, void* out, uint64_
   p.lut = c->have_lut ? c->d_lut : nullptr;
   p.out = out;
   p.fast_table = c->d_fast;
+  p.fast_waves = getenv("SONO_FAST_WAVES") ? (uint32_t)atoi(getenv("SONO_FAST_WAVES")) : 16;
   p.scale_mode = c->cfg.scale_mode;
   p.out_kind = c->cfg.out_kind;
   p.in_kind = c->cfg.in_kind;

@@ -30,8 +30,7 @@ namespace sono {
 namespace fast1024 {
 
 constexpr int kN = 1024;
-constexpr int kThreads = 1024;                     // 16 independent wavefronts share one twiddle matrix
-constexpr int kWaves = kThreads / 64;
+constexpr int kMaxWaves = 16;                      // independent wavefronts per workgroup (one workgroup per CU)
 constexpr int kPlaneStride = 36;                   // floats per transpose row: rows stay 16-B aligned and 16 consecutive
                                                    // rows start on 16 distinct 4-bank groups (ds_read_b128 conflict-free)
 constexpr int kFftBufBytes = 32 * kPlaneStride * 4;  // 4608: one plane of the transpose, or one half of the epilogue
@@ -39,7 +38,7 @@ constexpr int kMirrorOffset = 256 * 8;             // epilogue: Z[k] in [0, 2048
 static_assert(kMirrorOffset + 257 * 8 <= kFftBufBytes, "epilogue half must fit the transpose buffer");
 constexpr int kTwBytes = 32 * 32 * 8;
 constexpr int kWinBytes = 32 * kPlaneStride * 4;   // window as [l][kPlaneStride]: lane l reads w[32a + l], a = 0..31, as 8 x 16 B
-constexpr int kLdsBytes = kTwBytes + kWinBytes + kWaves * 2 * kFftBufBytes;  // 160256: one workgroup per CU
+constexpr int lds_bytes(int waves) { return kTwBytes + kWinBytes + waves * 2 * kFftBufBytes; }  // 16 waves: 160256
 
 // cos/sin(2*pi*j/32), j = 0..15
 __device__ constexpr float kC32[16] = {1.0f,          0.98078528040323044913f, 0.92387953251128675613f, 0.83146961230254523708f,
@@ -121,9 +120,12 @@ __device__ __forceinline__ uint32_t put_index(float msq, const FastScale& fs, ui
 
 // HOP32 > 0: hop == 32*HOP32, so frame B's sample 32a+l is frame A's sample 32(a+HOP32)+l and one
 // run of 32+HOP32 loads feeds both frames.  HOP32 == 0: any hop, two runs of 32 loads.
-template <bool PLUGIN, typename In, int HOP32>
-__global__ __launch_bounds__(kThreads, kThreads / 256) void stft1024_u8_kernel(StftParams p, FastScale fs,
-                                                                             const float2* __restrict__ tw_table) {
+// WAVES: wavefronts per workgroup (16 fills a CU; 12 leaves a quarter of the registers and 36 KiB of
+// LDS for a co-resident kernel).
+template <bool PLUGIN, typename In, int HOP32, int WAVES>
+__global__ __launch_bounds__(WAVES * 64, 4) void stft1024_u8_kernel(StftParams p, FastScale fs,
+                                                                    const float2* __restrict__ tw_table) {
+  constexpr int kThreads = WAVES * 64, kWaves = WAVES;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float2* tw_lds = reinterpret_cast<float2*>(smem);
   float* win_lds = reinterpret_cast<float*>(smem + kTwBytes);
@@ -305,7 +307,8 @@ int launch_stft_fast(const StftParams& p, void* stream_v) {
   fs.b -= 2.0f * fs.a;
   fs.db_off -= 2.0f * 3.0102999566f;
   const uint64_t npairs = (p.nframes + 1) / 2;
-  const uint64_t need = (npairs + 2 * kWaves - 1) / (2 * kWaves);
+  const int waves = (p.fast_waves == 12) ? 12 : 16;
+  const uint64_t need = (npairs + 2 * waves - 1) / (2 * waves);
   int cus = 256;
   {
     int dev = 0;
@@ -315,13 +318,17 @@ int launch_stft_fast(const StftParams& p, void* stream_v) {
   }
   const uint32_t grid = (uint32_t)(need < (uint64_t)cus ? need : (uint64_t)cus);  // persistent: one workgroup per CU
   const float2* table = reinterpret_cast<const float2*>(p.fast_table);
+#define SONO_LAUNCH_W(PLUGIN, In, H, W)                                                                     \
+  do {                                                                                                      \
+    auto kern = stft1024_u8_kernel<PLUGIN, In, H, W>;                                                       \
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                            lds_bytes(W)) != hipSuccess)                                                    \
+      return SONO_ERR_DEVICE;                                                                               \
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(W * 64), lds_bytes(W), stream, p, fs, table);                 \
+  } while (0)
 #define SONO_LAUNCH_H(PLUGIN, In, H)                                                                        \
   do {                                                                                                      \
-    auto kern = stft1024_u8_kernel<PLUGIN, In, H>;                                                          \
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, \
-                            kLdsBytes) != hipSuccess)                                                       \
-      return SONO_ERR_DEVICE;                                                                               \
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), kLdsBytes, stream, p, fs, table);                  \
+    if (waves == 12) SONO_LAUNCH_W(PLUGIN, In, H, 12); else SONO_LAUNCH_W(PLUGIN, In, H, 16);               \
   } while (0)
 #define SONO_LAUNCH(PLUGIN, In)                                                                             \
   do {                                                                                                      \
@@ -337,6 +344,7 @@ int launch_stft_fast(const StftParams& p, void* stream_v) {
   }
 #undef SONO_LAUNCH
 #undef SONO_LAUNCH_H
+#undef SONO_LAUNCH_W
   return hipGetLastError() == hipSuccess ? SONO_OK : SONO_ERR_DEVICE;
 }
 

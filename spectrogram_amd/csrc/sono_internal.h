@@ -35,6 +35,7 @@ struct StftParams {
   const uint32_t* lut;    // device, 256 packed RGBA (little endian r | g<<8 | b<<16 | a<<24), or nullptr = grey
   void* out;              // device
   const void* fast_table; // device: per-size twiddle matrix of the fast kernels, or nullptr
+  uint32_t fast_waves;    // wavefronts per workgroup of the fast kernel: 16 (default) or 12
   uint32_t scale_mode, out_kind, in_kind;
   double gain_db, range_db;
 };
