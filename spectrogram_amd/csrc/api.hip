@@ -186,7 +186,13 @@ sono_ctx* sono_create(int device, const sono_config* cfg) {
   if ((e = hipEventCreate(&c->ev_stop)) != hipSuccess) return bail("hipEventCreate", e);
   if ((e = hipMalloc((void**)&c->d_window, sizeof(float) * n)) != hipSuccess) return bail("hipMalloc(window)", e);
   if ((e = hipMalloc(&c->d_tw, sizeof(double) * 2 * n)) != hipSuccess) return bail("hipMalloc(twiddles)", e);
-  if ((e = hipMalloc((void**)&c->d_lut, 1024)) != hipSuccess) return bail("hipMalloc(lut)", e);
+  // entries [0, 256): the caller's colour map; [256, 512): the grey ramp used when none is set
+  if ((e = hipMalloc((void**)&c->d_lut, 2048)) != hipSuccess) return bail("hipMalloc(lut)", e);
+  {
+    uint32_t grey[256];
+    for (uint32_t i = 0; i < 256; ++i) grey[i] = i * 0x010101u | 0xFF000000u;
+    if ((e = hipMemcpy(c->d_lut + 256, grey, 1024, hipMemcpyHostToDevice)) != hipSuccess) return bail("hipMemcpy(lut)", e);
+  }
   if (upload_tables(c) != SONO_OK) {
     g_create_error = c->err;
     sono_destroy(c);
@@ -305,7 +311,7 @@ int sono_stft_async(sono_ctx* c, const void* pcm, uint64_t L, void* out, uint64_
   p.lut = c->have_lut ? c->d_lut : nullptr;
   p.out = out;
   p.fast_table = c->d_fast;
-  p.fast_waves = getenv("SONO_FAST_WAVES") ? (uint32_t)atoi(getenv("SONO_FAST_WAVES")) : 16;
+  p.tile_scratch = nullptr;
   p.scale_mode = c->cfg.scale_mode;
   p.out_kind = c->cfg.out_kind;
   p.in_kind = c->cfg.in_kind;
@@ -317,6 +323,19 @@ int sono_stft_async(sono_ctx* c, const void* pcm, uint64_t L, void* out, uint64_
   auto launch = [&](const StftParams& q) -> int {
     if ((q.frame0 + q.nframes - 1) * q.hop + q.n > q.n_samples) return fail(c, SONO_ERR_ARG, "frame range exceeds the signal");
     int r = 1;
+    StftParams qq = q;
+    if (!qq.lut) qq.lut = c->d_lut + 256;
+    if (fast_eligible(c) && q.out_kind == SONO_OUT_RGBA8 && fast_rgba_available(qq) && !getenv("SONO_RGBA_TWO_PASS")) {
+      // the fast kernel writes the image itself; it needs a small scratch buffer for its wavefront tiles
+      int rc2 = ensure(c, &c->d_aux, &c->d_aux_bytes, fast_rgba_scratch_bytes());
+      if (rc2 != SONO_OK) return rc2;
+      StftParams u = q;
+      u.tile_scratch = c->d_aux;
+      if (!u.lut) u.lut = c->d_lut + 256;
+      r = launch_stft_fast(u, c->stream);
+      if (r != SONO_OK) return fail(c, r, "kernel launch failed: %s", hipGetErrorString(hipGetLastError()));
+      return SONO_OK;
+    }
     if (fast_eligible(c) && q.out_kind == SONO_OUT_RGBA8 && q.row_of_bin0 == (int32_t)q.bin_hi - 1) {
       // RGBA through the fast kernel: colour indices of a chunk of frames go to a context-owned
       // [frame][bin] buffer small enough to stay in the Infinity Cache, then a transposing LUT

@@ -23,6 +23,9 @@
 #include <cmath>
 #include <vector>
 
+#ifndef SONO_EXP
+#define SONO_EXP 0
+#endif
 #include "sono_device.h"
 #include "sono_internal.h"
 
@@ -39,6 +42,15 @@ static_assert(kMirrorOffset + 257 * 8 <= kFftBufBytes, "epilogue half must fit t
 constexpr int kTwBytes = 32 * 32 * 8;
 constexpr int kWinBytes = 32 * kPlaneStride * 4;   // window as [l][kPlaneStride]: lane l reads w[32a + l], a = 0..31, as 8 x 16 B
 constexpr int lds_bytes(int waves) { return kTwBytes + kWinBytes + waves * 2 * kFftBufBytes; }  // 16 waves: 160256
+// RGBA output: a workgroup round covers 256 consecutive frames (16 per wavefront, four iterations =
+// 64 frame groups of 4); their colour indices are parked in one of the workgroup's two slots of a
+// global scratch buffer as [reader wavefront 16][frame group 64][bin quad 8] x 16 bytes (four frames x
+// four bins), 128 KiB, which stays in L2 / Infinity Cache.
+constexpr int kTileFrames = 16;                    // frames per wavefront and round
+constexpr int kRoundFrames = kMaxWaves * kTileFrames;
+constexpr int kRoundBytes = 128 * kRoundFrames * 4;
+constexpr int kLutBytes = 1024;
+typedef uint32_t u32x4_unaligned __attribute__((ext_vector_type(4), aligned(4)));
 
 // cos/sin(2*pi*j/32), j = 0..15
 __device__ constexpr float kC32[16] = {1.0f,          0.98078528040323044913f, 0.92387953251128675613f, 0.83146961230254523708f,
@@ -118,14 +130,80 @@ __device__ __forceinline__ uint32_t put_index(float msq, const FastScale& fs, ui
   }
 }
 
+// Writes one quarter (`part` = 0..3) of a workgroup round (256 frames starting at frame `frame0`,
+// indices in `slot`) to the RGBA image.  Wavefront w owns the 32 bins 32w .. 32w+31 (32 image rows) and
+// writes the eight rows of bins 32w + 8*part .. +7 per quarter, complete: per step u lane j reads the
+// bin quad 2*part + (j & 1) of the frame group 32u + (j >> 1), i.e. 4 bins x 4 frames, and stores four
+// 16-byte pixel runs; 32 lanes form a 512-byte run of one row and the two steps complete its 1-KiB run,
+// so that sectors are whole when they leave L2 (up to the ends of the run, which the neighbouring
+// workgroup completes).  Addresses are a wave-uniform base plus a 32-bit lane offset.
+__device__ __forceinline__ void flush_quarter(const StftParams& p, const uint32_t* __restrict__ slot,
+                                              const uint32_t* lut_lds, uint64_t frame0, int part, int wave, int lane) {
+  // Everything here is invariant in the caller's frame loop; computing it in place is cheap, while
+  // hoisted copies would occupy registers that the FFT needs.
+  asm volatile("" : "+s"(wave));
+  asm volatile("" : "+v"(lane));
+  const int qsel = lane & 1, fsel = lane >> 1;
+  const uint4* sp = reinterpret_cast<const uint4*>(slot) + wave * (64 * 8) + fsel * 8 + 2 * part + qsel;
+  uint4 q[2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) q[u] = sp[u * 32 * 8];
+  const int64_t width4 = (int64_t)p.width * 4;
+  const uint32_t voff = (uint32_t)(4 - 4 * qsel) * (uint32_t)width4 + 16u * fsel;
+  const bool whole = frame0 + kRoundFrames <= p.nframes;  // workgroup-uniform
+  const int bin0 = 32 * wave + 8 * part;                  // wave-uniform; the band is made of 16-bin groups
+  if (bin0 < (int)p.bin_lo || bin0 >= (int)p.bin_hi) return;
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const uint64_t fl = frame0 + 128 * u + 4 * fsel;  // this lane's first frame
+    const int nvalid = fl >= p.nframes ? 0 : (p.nframes - fl >= 4 ? 4 : (int)(p.nframes - fl));
+    // row of bin (bin0 + 4 + i), column of frame group 32u
+    uint8_t* __restrict__ base = reinterpret_cast<uint8_t*>(p.out) + (int64_t)(p.col0 + frame0 + 128 * u) * 4 +
+                                 (int64_t)(p.row_of_bin0 - bin0 - 4) * width4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      u32x4_unaligned px;
+      px.x = lut_lds[(q[u].x >> (8 * i)) & 255u];
+      px.y = lut_lds[(q[u].y >> (8 * i)) & 255u];
+      px.z = lut_lds[(q[u].z >> (8 * i)) & 255u];
+      px.w = lut_lds[(q[u].w >> (8 * i)) & 255u];
+      uint8_t* dst = base - (int64_t)i * width4 + voff;
+#if SONO_EXP == 1
+      if (px.x == 0x12345678u)
+#endif
+      if (whole) {
+        *reinterpret_cast<u32x4_unaligned*>(dst) = px;
+      } else {  // the last round of the recording
+        uint32_t* d = reinterpret_cast<uint32_t*>(dst);
+        if (nvalid > 0) d[0] = px.x;
+        if (nvalid > 1) d[1] = px.y;
+        if (nvalid > 2) d[2] = px.z;
+        if (nvalid > 3) d[3] = px.w;
+      }
+    }
+  }
+}
+
 // HOP32 > 0: hop == 32*HOP32, so frame B's sample 32a+l is frame A's sample 32(a+HOP32)+l and one
 // run of 32+HOP32 loads feeds both frames.  HOP32 == 0: any hop, two runs of 32 loads.
-// WAVES: wavefronts per workgroup (16 fills a CU; 12 leaves a quarter of the registers and 36 KiB of
-// LDS for a co-resident kernel).
-template <bool PLUGIN, typename In, int HOP32, int WAVES>
-__global__ __launch_bounds__(WAVES * 64, 4) void stft1024_u8_kernel(StftParams p, FastScale fs,
-                                                                    const float2* __restrict__ tw_table) {
-  constexpr int kThreads = WAVES * 64, kWaves = WAVES;
+//
+// RGBA: the output is the image [row = row_of_bin0 - bin][column = col0 + frame] of LUT colours
+// instead of [frame][bin] indices.  A frame is one image COLUMN, so writing frames as they are
+// finished would scatter 16-byte pieces over 512 rows; partial 64-byte sectors cost the memory a
+// read-modify-write, and a store instruction that touches many cache lines is slow in the CU.  So the
+// workgroup parks the indices of a round (256 consecutive frames) in a scratch slot that stays in
+// cache, meets at ONE barrier per round, and during the next round every wavefront writes its 32
+// image rows of the finished round, a quarter per iteration (flush_quarter), from the other slot.
+// The stores of a quarter are issued after the next iteration's sample loads, so neither waits for
+// the other.  The two half-wavefronts first swap registers (v_permlane32_swap) so that a lane holds
+// the same four bins of all four frames of the iteration: one 16-byte scratch store per lane and
+// epilogue half, 128 bytes (one line) per eight lanes.
+template <bool PLUGIN, typename In, int HOP32, bool RGBA>
+__global__ __launch_bounds__(kMaxWaves * 64, 4) void stft1024_u8_kernel(StftParams p, FastScale fs,
+                                                                        const float2* __restrict__ tw_table,
+                                                                        uint8_t* __restrict__ tiles) {
+  constexpr int kThreads = kMaxWaves * 64, kWaves = kMaxWaves;
+  constexpr int kTileIters = RGBA ? kTileFrames / 4 : 1;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float2* tw_lds = reinterpret_cast<float2*>(smem);
   float* win_lds = reinterpret_cast<float*>(smem + kTwBytes);
@@ -133,9 +211,14 @@ __global__ __launch_bounds__(WAVES * 64, 4) void stft1024_u8_kernel(StftParams p
     tw_lds[i] = tw_table[i];
     win_lds[(i & 31) * kPlaneStride + (i >> 5)] = p.window[i];  // sample n = 32a + l at [l][a]
   }
+  uint32_t* lut_lds = reinterpret_cast<uint32_t*>(smem + lds_bytes(kMaxWaves));
+  if constexpr (RGBA) {
+    for (int i = threadIdx.x; i < 256; i += kThreads) lut_lds[i] = p.lut[i];
+  }
   __syncthreads();
 
-  const int lane = threadIdx.x & 63, l = lane & 31, h = lane >> 5, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, l = lane & 31, h = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // lets wave-uniform addresses live in SGPRs
   unsigned char* fbuf = smem + kTwBytes + kWinBytes + (wave * 2 + h) * kFftBufBytes;
   const float4* win_row = reinterpret_cast<const float4*>(win_lds + l * kPlaneStride);
   float* plane = reinterpret_cast<float*>(fbuf);                   // transpose view: [k1][kPlaneStride] floats
@@ -149,44 +232,80 @@ __global__ __launch_bounds__(WAVES * 64, 4) void stft1024_u8_kernel(StftParams p
   const uint32_t per = gridDim.x >> 3;
   const uint32_t vb = (gridDim.x & 7) ? blockIdx.x : (blockIdx.x & 7) * per + (blockIdx.x >> 3);
 
-  for (uint64_t it = 0;; ++it) {
-    const uint64_t pair0 = ((it * gridDim.x + vb) * kWaves + wave) * 2;
-    if (pair0 >= npairs) break;  // wave-uniform
-    const uint64_t pair = pair0 + h;
-    // frames (f0, f0+1) form the complex input; st_a / st_b say which of the two results are stored.
-    // An odd last frame is computed as the second member of the pair before it.
-    uint64_t f0 = 2 * pair;
-    bool st_a = pair < npairs, st_b = st_a;
-    if (!st_a) {
-      f0 = 2 * pair0;
-    } else if (f0 + 1 >= p.nframes) {
-      f0 -= 1;
-      st_a = false;
-    }
-    const In* xa = x + (p.frame0 + f0) * p.hop + l;
+  uint32_t* slots = reinterpret_cast<uint32_t*>(tiles + (size_t)blockIdx.x * 2 * kRoundBytes);
+  // RGBA: every workgroup of the grid runs the same number of rounds and every wavefront goes through
+  // every round (with or without frames of its own), because the round ends in workgroup barriers
+  const uint64_t ntiles = (p.nframes + kTileFrames - 1) / kTileFrames;
+  const uint64_t rounds = (ntiles + (uint64_t)gridDim.x * kWaves - 1) / ((uint64_t)gridDim.x * kWaves);
 
-    float re[32], im[32];
-    float win[32];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const float4 v = win_row[j];
-      win[4 * j] = v.x; win[4 * j + 1] = v.y; win[4 * j + 2] = v.z; win[4 * j + 3] = v.w;
+  // Iteration `it` of this wavefront: unit = four consecutive frames (two per half-wavefront); a
+  // wavefront takes kTileIters consecutive units per round.  Frames (f0, f0+1) form the complex input;
+  // st_a / st_b say which of the two results are stored.  An odd last frame is computed as the second
+  // member of the pair before it (shifted).  Returns false when the wavefront has no frame left.
+  struct Unit {
+    uint64_t f0;
+    bool active, st_a, st_b, shifted;
+  };
+  auto locate = [&](uint64_t it) -> Unit {
+    Unit u;
+    const uint64_t tile_id = ((it / kTileIters) * gridDim.x + vb) * kWaves + wave;
+    const uint64_t pair0 = (tile_id * kTileIters + it % kTileIters) * 2;
+    u.active = pair0 < npairs;  // wave-uniform
+    const uint64_t pair = pair0 + h;
+    u.f0 = 2 * pair;
+    u.st_a = u.st_b = pair < npairs;
+    u.shifted = false;
+    if (!u.st_a) {
+      u.f0 = 2 * pair0;
+    } else if (u.f0 + 1 >= p.nframes) {
+      u.f0 -= 1;
+      u.st_a = false;
+      u.shifted = true;
     }
+    return u;
+  };
+  // The samples of an iteration are loaded one iteration ahead (into raw), so that their latency and,
+  // in RGBA rounds, the drain of the image stores issued in between overlap with the arithmetic.
+  constexpr int kRaw = HOP32 > 0 ? 32 + HOP32 : 64;
+  float raw[kRaw];
+  auto fetch = [&](const Unit& u) {
+    const In* xa = x + (p.frame0 + u.f0) * p.hop + l;
     if constexpr (HOP32 > 0) {
-      float raw[32 + HOP32];
 #pragma unroll
       for (int a = 0; a < 32 + HOP32; ++a) raw[a] = ld<In>(xa, 32 * a);
-#pragma unroll
-      for (int a = 0; a < 32; ++a) {
-        re[brev5(a)] = raw[a] * win[a];
-        im[brev5(a)] = raw[a + HOP32] * win[a];
-      }
     } else {
       const In* xb = xa + p.hop;
 #pragma unroll
       for (int a = 0; a < 32; ++a) {
-        re[brev5(a)] = ld<In>(xa, 32 * a) * win[a];
-        im[brev5(a)] = ld<In>(xb, 32 * a) * win[a];
+        raw[a] = ld<In>(xa, 32 * a);
+        raw[32 + a] = ld<In>(xb, 32 * a);
+      }
+    }
+  };
+  Unit cur = locate(0);
+  if (cur.active) fetch(cur);
+  // RGBA: one more round than there are frames for, which only writes out the last slot
+  for (uint64_t it = 0; !RGBA || it < (rounds + 1) * kTileIters; ++it) {
+    if (!RGBA && !cur.active) break;
+    uint32_t* slot = slots + ((it / kTileIters) & 1) * (kRoundBytes / 4);
+    const Unit nxt = locate(it + 1);
+    do {
+    if (!cur.active) break;
+    const uint64_t f0 = cur.f0;
+    const bool st_a = cur.st_a, st_b = cur.st_b, shifted = cur.shifted;
+
+    float re[32], im[32];
+    {
+      float win[32];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float4 v = win_row[j];
+        win[4 * j] = v.x; win[4 * j + 1] = v.y; win[4 * j + 2] = v.z; win[4 * j + 3] = v.w;
+      }
+#pragma unroll
+      for (int a = 0; a < 32; ++a) {
+        re[brev5(a)] = raw[a] * win[a];
+        im[brev5(a)] = raw[a + (HOP32 > 0 ? HOP32 : 32)] * win[a];
       }
     }
     fft32(re, im);  // Y_l[k1]
@@ -244,6 +363,7 @@ __global__ __launch_bounds__(WAVES * 64, 4) void stft1024_u8_kernel(StftParams p
       }
       if (l == 0) mbuf[0] = make_float2(re[P ? 24 : 0], im[P ? 24 : 0]);
       wave_sync();
+      uint32_t wa2[2], wb2[2];
 #pragma unroll
       for (int g = 0; g < 2; ++g) {
         const int idx = 4 * (l + 32 * g);
@@ -265,13 +385,48 @@ __global__ __launch_bounds__(WAVES * 64, 4) void stft1024_u8_kernel(StftParams p
         SONO_BIN(2, z23.x, z23.y, q23.x, q23.y)
         SONO_BIN(3, z23.z, z23.w, q23.z, q23.w)
 #undef SONO_BIN
-        if (k >= (int)p.bin_lo && k < (int)p.bin_hi) {
+        if constexpr (RGBA) {
+          wa2[g] = shifted ? wb : wa;  // an odd last frame was computed as B: it belongs in the A slot
+          wb2[g] = wb;
+        } else if (k >= (int)p.bin_lo && k < (int)p.bin_hi) {
           const uint32_t col = k - p.out_bin0;
           if (st_a) *reinterpret_cast<uint32_t*>(out + row_a + col) = wa;
           if (st_b) *reinterpret_cast<uint32_t*>(out + row_b + col) = wb;
         }
       }
+      if constexpr (RGBA) {
+        // before: lanes of half h hold frames (2h, 2h+1) of the iteration for the bin quads l (g = 0) and
+        // 32 + l (g = 1); after: lane (l, h) holds the quad l + 32h of all four frames
+        const auto sa = __builtin_amdgcn_permlane32_swap(wa2[0], wa2[1], false, false);
+        const auto sb = __builtin_amdgcn_permlane32_swap(wb2[0], wb2[1], false, false);
+        const int kq = 64 * P + l + 32 * h;               // reader wavefront kq >> 3, its quad kq & 7
+        const int fg = 4 * wave + (int)(it % kTileIters);  // frame group of the round
+#if SONO_EXP == 2
+        if (sa[0] == 0x12345678u)
+#endif
+        if (4 * kq >= (int)p.bin_lo && 4 * kq < (int)p.bin_hi)
+          reinterpret_cast<uint4*>(slot)[((kq >> 3) * 64 + fg) * 8 + (kq & 7)] = make_uint4(sa[0], sb[0], sa[1], sb[1]);
+      }
       wave_sync();  // the buffer is rewritten by the next half / the next iteration's transpose
+    }
+    } while (0);
+    if (nxt.active) {
+      fetch(nxt);
+    } else {  // (a constant, so that this iteration's samples do not stay live as the fall-through value)
+#pragma unroll
+      for (int a = 0; a < kRaw; ++a) raw[a] = 0.0f;
+    }
+    cur = nxt;
+    if constexpr (RGBA) {
+      const uint64_t round = it / kTileIters;
+      if (round > 0) {  // a quarter of the previous round, from the other slot
+        const uint64_t frame0 = ((round - 1) * gridDim.x + vb) * kRoundFrames;
+        if (frame0 < p.nframes)
+          flush_quarter(p, slots + ((round - 1) & 1) * (kRoundBytes / 4), lut_lds, frame0, (int)(it % kTileIters), wave, lane);
+      }
+      // End of a round: this round's slot is complete (and visible: one CU, one L1), and every
+      // wavefront is done reading the other slot, which the next round overwrites.
+      if (it % kTileIters == kTileIters - 1) __syncthreads();
     }
   }
 }
@@ -297,9 +452,34 @@ bool fast_u8_available(const StftParams& p) {
   return true;
 }
 
+// The fused image output needs whole 16-bin groups, the flipped full-height row mapping and store
+// offsets (up to 48 image rows) that fit 32 bits.
+bool fast_rgba_available(const StftParams& p) {
+  if (p.n != 1024 || !p.fast_table || p.nframes < 16) return false;
+  if ((p.bin_lo & 15) || (p.bin_hi & 15) || p.bin_lo >= p.bin_hi) return false;
+  if (p.row_of_bin0 != (int32_t)p.bin_hi - 1) return false;
+  if (p.width == 0 || p.width > ((uint64_t)1 << 24) || !p.lut) return false;
+  return true;
+}
+
+static int cu_count() {
+  int dev = 0;
+  hipDeviceProp_t prop;
+  if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+    return prop.multiProcessorCount;
+  return 256;
+}
+
+uint64_t fast_rgba_scratch_bytes() { return (uint64_t)cu_count() * 2 * fast1024::kRoundBytes; }
+
 int launch_stft_fast(const StftParams& p, void* stream_v) {
   using namespace fast1024;
-  if (p.out_kind != SONO_OUT_U8_INDEX || !fast_u8_available(p)) return 1;
+  const bool rgba = p.out_kind == SONO_OUT_RGBA8;
+  if (rgba) {
+    if (!fast_rgba_available(p) || !p.tile_scratch) return 1;
+  } else {
+    if (p.out_kind != SONO_OUT_U8_INDEX || !fast_u8_available(p)) return 1;
+  }
   if (reinterpret_cast<uintptr_t>(p.out) & 3) return 1;
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_v);
   FastScale fs = make_fast_scale(p.scale_mode, p.n, p.gain_db, p.range_db);
@@ -307,28 +487,25 @@ int launch_stft_fast(const StftParams& p, void* stream_v) {
   fs.b -= 2.0f * fs.a;
   fs.db_off -= 2.0f * 3.0102999566f;
   const uint64_t npairs = (p.nframes + 1) / 2;
-  const int waves = (p.fast_waves == 12) ? 12 : 16;
-  const uint64_t need = (npairs + 2 * waves - 1) / (2 * waves);
-  int cus = 256;
-  {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
-      cus = prop.multiProcessorCount;
-  }
+  // one wavefront handles 2 pairs per iteration (u8) or one 16-frame tile per 4 iterations (RGBA)
+  const uint64_t per_wg = rgba ? (uint64_t)kRoundFrames / 2 : (uint64_t)kMaxWaves * 2;
+  const uint64_t need = (npairs + per_wg - 1) / per_wg;
+  const int cus = cu_count();
   const uint32_t grid = (uint32_t)(need < (uint64_t)cus ? need : (uint64_t)cus);  // persistent: one workgroup per CU
   const float2* table = reinterpret_cast<const float2*>(p.fast_table);
-#define SONO_LAUNCH_W(PLUGIN, In, H, W)                                                                     \
+  uint8_t* tiles = reinterpret_cast<uint8_t*>(p.tile_scratch);
+  const int lds_total = lds_bytes(kMaxWaves) + (rgba ? kLutBytes : 0);
+#define SONO_LAUNCH_R(PLUGIN, In, H, R)                                                                     \
   do {                                                                                                      \
-    auto kern = stft1024_u8_kernel<PLUGIN, In, H, W>;                                                       \
+    auto kern = stft1024_u8_kernel<PLUGIN, In, H, R>;                                                       \
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, \
-                            lds_bytes(W)) != hipSuccess)                                                    \
+                            lds_total) != hipSuccess)                                                       \
       return SONO_ERR_DEVICE;                                                                               \
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(W * 64), lds_bytes(W), stream, p, fs, table);                 \
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kMaxWaves * 64), lds_total, stream, p, fs, table, tiles);     \
   } while (0)
 #define SONO_LAUNCH_H(PLUGIN, In, H)                                                                        \
   do {                                                                                                      \
-    if (waves == 12) SONO_LAUNCH_W(PLUGIN, In, H, 12); else SONO_LAUNCH_W(PLUGIN, In, H, 16);               \
+    if (rgba) SONO_LAUNCH_R(PLUGIN, In, H, true); else SONO_LAUNCH_R(PLUGIN, In, H, false);                 \
   } while (0)
 #define SONO_LAUNCH(PLUGIN, In)                                                                             \
   do {                                                                                                      \
@@ -344,7 +521,7 @@ int launch_stft_fast(const StftParams& p, void* stream_v) {
   }
 #undef SONO_LAUNCH
 #undef SONO_LAUNCH_H
-#undef SONO_LAUNCH_W
+#undef SONO_LAUNCH_R
   return hipGetLastError() == hipSuccess ? SONO_OK : SONO_ERR_DEVICE;
 }
 

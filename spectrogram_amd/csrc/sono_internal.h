@@ -35,7 +35,7 @@ struct StftParams {
   const uint32_t* lut;    // device, 256 packed RGBA (little endian r | g<<8 | b<<16 | a<<24), or nullptr = grey
   void* out;              // device
   const void* fast_table; // device: per-size twiddle matrix of the fast kernels, or nullptr
-  uint32_t fast_waves;    // wavefronts per workgroup of the fast kernel: 16 (default) or 12
+  void* tile_scratch;     // device: fast_rgba_scratch_bytes() of scratch for the fused RGBA output, or nullptr
   uint32_t scale_mode, out_kind, in_kind;
   double gain_db, range_db;
 };
@@ -52,6 +52,9 @@ int launch_colorize(const uint8_t* frames, uint64_t ncols, uint32_t bins, uint32
                     const uint32_t* lut, uint8_t* rgba, uint64_t img_width, uint64_t col0, void* hip_stream);
 // True when launch_stft_fast has a kernel for this size / layout with uint8 output.
 bool fast_u8_available(const StftParams& p);
+// True when launch_stft_fast can write the RGBA image itself (given tile_scratch).
+bool fast_rgba_available(const StftParams& p);
+uint64_t fast_rgba_scratch_bytes();
 int launch_frame_peaks(const uint8_t* idx, uint64_t frames, uint32_t bins, int32_t* peak_bin, uint8_t* peak_idx,
                        void* hip_stream);
 
