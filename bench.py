@@ -3,14 +3,16 @@
 
 Workload (BASELINE.json configs[1]): one hour of synthetic 384 kHz mono bat-call PCM per GPU,
 resident in HBM before the timed region; one step = one pass of the worker-path transform
-(spectrogramWorker.js semantics: worker Hann, accurate twiddles, log10|X|/5 quantiser) over the
-whole recording.  Ranks are independent (one recording each, no collective in the data path).
+(spectrogramWorker.js semantics: worker Hann, accurate twiddles, log10|X|/5 quantiser, colour LUT,
+RGBA ImageData layout) over the whole recording.  `--out u8` stops at the colour indices
+([frame][bin] uint8, what the plugin's getFrequencies returns); it is reported under `variants`.  Ranks are independent (one recording each, no collective in the data path).
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--out u8|rgba] [--seconds S]
 
 Prints ONE JSON line (rank 0).  `value` is whole-job Msamples/s.  `roofline` prices the dominant
 kernel against HBM with algorithmic bytes (each input sample once + each output byte once) over
-its average launch time measured with HIP events on the launch stream.  `cpu_baseline` is the CPU
+its average launch time measured with HIP events on the launch stream; `traffic` is the fabric-side
+byte count of one launch from the committed counter profile of the same workload (profiles/), if any.  `cpu_baseline` is the CPU
 checker in oracle/ (a C restatement of the reference's worker) timed on the host cores on a bounded
 sample of the same signal.
 """
@@ -53,12 +55,29 @@ def synth_chunk(torch, dev, start, count, seed):
     return x
 
 
+def profiled_traffic(out_name, samples):
+    """HBM-side bytes of one launch of the dominant kernel, from the PMC passes committed under
+    profiles/ (tools/profile.sh writes traffic.json); None when there is no profile of this workload."""
+    best = None
+    for d in sorted(os.listdir(os.path.join(ROOT, "profiles"))) if os.path.isdir(os.path.join(ROOT, "profiles")) else []:
+        f = os.path.join(ROOT, "profiles", d, "traffic.json")
+        if os.path.isfile(f):
+            try:
+                t = json.load(open(f))
+            except ValueError:
+                continue
+            e = t.get(out_name)
+            if e and int(e.get("samples", 0)) == int(samples):
+                best = int(e["bytes_per_launch"])
+    return best
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--out", choices=["u8", "rgba"], default="u8")
+    ap.add_argument("--out", choices=["u8", "rgba"], default="rgba")
     ap.add_argument("--seconds", type=int, default=3600, help="recording length per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-variants", action="store_true")
@@ -159,7 +178,7 @@ def main():
             },
             "roofline": {
                 "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": profiled_traffic(args.out, L),
                 "kernel_ms": round(kern_ms, 4), "algorithmic_bytes_per_launch": int(algo_bytes),
                 "bytes_per_sample": round(algo_bytes / L, 3),
             },
@@ -181,7 +200,7 @@ def main():
         t0 = time.perf_counter()
         oracle.worker_render(probe, FFT_N, 75.0, None, threads=cores)
         rate = len(probe) / (time.perf_counter() - t0)            # samples/s on `cores` threads
-        secs = int(max(4, min(120, rate * 12 / SAMPLE_RATE)))       # about 12 s of CPU work
+        secs = int(max(4, min(args.seconds, rate * 15 / SAMPLE_RATE)))  # about 15 s of CPU work
         sample = x[: secs * SAMPLE_RATE].cpu().numpy()
         t0 = time.perf_counter()
         oracle.worker_render(sample, FFT_N, 75.0, None, threads=cores)

@@ -13,26 +13,25 @@
 // Z[N-k] together for the epilogue.  Each wavefront owns its slice of LDS, so the steady-state
 // loop has no workgroup barrier.  The epilogue fuses |X|^2 -> log2 -> quantiser -> packed uint8.
 //
-// Occupancy is what this kernel lives on (one wavefront issues at most one VALU instruction per four
-// cycles and waits on LDS about half the time), so the per-wavefront LDS slice is kept at 9 KiB: the
-// transpose moves the real and the imaginary plane one after the other through the same 4.5 KiB
-// buffer and the epilogue handles the bins in two halves.  One 1024-thread workgroup (16 independent
-// wavefronts = 4 per SIMD, <= 128 VGPRs) per CU: 8 KiB twiddle matrix W_1024^(l*k1) + 4.5 KiB window + 32 x 4608 B.
+// The kernel is bound by vector-ALU issue (about 1300 VALU instructions per iteration, which is close
+// to the operation count of the algorithm) with the LDS pipe about half busy, so it lives on
+// occupancy: the per-wavefront LDS slice is kept at 9 KiB (the transpose moves the real and the
+// imaginary plane one after the other through the same 4.5 KiB buffer and the epilogue handles the
+// bins in two halves) and registers at <= 128, which gives one 1024-thread workgroup (16 independent
+// wavefronts = 4 per SIMD) per CU: 8 KiB twiddle matrix W_1024^(l*k1) + 4.5 KiB window + 32 x 4608 B.
+// Packed FP32 (v_pk_fma_f32) was measured and does not pay here: it issues at 2/3 of the scalar rate
+// on this chip and the operand pairing costs moves.
 #include <hip/hip_runtime.h>
 
 #include <cmath>
 #include <vector>
 
-#ifndef SONO_EXP
-#define SONO_EXP 0
-#endif
 #include "sono_device.h"
 #include "sono_internal.h"
 
 namespace sono {
 namespace fast1024 {
 
-constexpr int kN = 1024;
 constexpr int kMaxWaves = 16;                      // independent wavefronts per workgroup (one workgroup per CU)
 constexpr int kPlaneStride = 36;                   // floats per transpose row: rows stay 16-B aligned and 16 consecutive
                                                    // rows start on 16 distinct 4-bank groups (ds_read_b128 conflict-free)
@@ -137,17 +136,23 @@ __device__ __forceinline__ uint32_t put_index(float msq, const FastScale& fs, ui
 // 16-byte pixel runs; 32 lanes form a 512-byte run of one row and the two steps complete its 1-KiB run,
 // so that sectors are whole when they leave L2 (up to the ends of the run, which the neighbouring
 // workgroup completes).  Addresses are a wave-uniform base plus a 32-bit lane offset.
-__device__ __forceinline__ void flush_quarter(const StftParams& p, const uint32_t* __restrict__ slot,
-                                              const uint32_t* lut_lds, uint64_t frame0, int part, int wave, int lane) {
+// first half of it: the two slot reads of lane `lane` for quarter `part`
+__device__ __forceinline__ void flush_quarter_load(uint4 (&q)[2], const uint32_t* __restrict__ slot, int part, int wave, int lane) {
+  asm volatile("" : "+s"(wave));
+  asm volatile("" : "+v"(lane));
+  const int qsel = lane & 1, fsel = lane >> 1;
+  const uint4* sp = reinterpret_cast<const uint4*>(slot) + wave * (64 * 8) + fsel * 8 + 2 * part + qsel;
+#pragma unroll
+  for (int u = 0; u < 2; ++u) q[u] = sp[u * 32 * 8];
+}
+// second half: colours and stores
+__device__ __forceinline__ void flush_quarter_store(const StftParams& p, const uint4 (&q)[2], const uint32_t* lut_lds,
+                                                    uint64_t frame0, int part, int wave, int lane) {
   // Everything here is invariant in the caller's frame loop; computing it in place is cheap, while
   // hoisted copies would occupy registers that the FFT needs.
   asm volatile("" : "+s"(wave));
   asm volatile("" : "+v"(lane));
   const int qsel = lane & 1, fsel = lane >> 1;
-  const uint4* sp = reinterpret_cast<const uint4*>(slot) + wave * (64 * 8) + fsel * 8 + 2 * part + qsel;
-  uint4 q[2];
-#pragma unroll
-  for (int u = 0; u < 2; ++u) q[u] = sp[u * 32 * 8];
   const int64_t width4 = (int64_t)p.width * 4;
   const uint32_t voff = (uint32_t)(4 - 4 * qsel) * (uint32_t)width4 + 16u * fsel;
   const bool whole = frame0 + kRoundFrames <= p.nframes;  // workgroup-uniform
@@ -168,9 +173,6 @@ __device__ __forceinline__ void flush_quarter(const StftParams& p, const uint32_
       px.z = lut_lds[(q[u].z >> (8 * i)) & 255u];
       px.w = lut_lds[(q[u].w >> (8 * i)) & 255u];
       uint8_t* dst = base - (int64_t)i * width4 + voff;
-#if SONO_EXP == 1
-      if (px.x == 0x12345678u)
-#endif
       if (whole) {
         *reinterpret_cast<u32x4_unaligned*>(dst) = px;
       } else {  // the last round of the recording
@@ -251,12 +253,17 @@ __global__ __launch_bounds__(kMaxWaves * 64, 4) void stft1024_u8_kernel(StftPara
     const uint64_t tile_id = ((it / kTileIters) * gridDim.x + vb) * kWaves + wave;
     const uint64_t pair0 = (tile_id * kTileIters + it % kTileIters) * 2;
     u.active = pair0 < npairs;  // wave-uniform
+    if (!u.active) {            // nothing left: point at frame 0 so that the sample loads stay in bounds
+      u.f0 = 0;
+      u.st_a = u.st_b = u.shifted = false;
+      return u;
+    }
     const uint64_t pair = pair0 + h;
     u.f0 = 2 * pair;
     u.st_a = u.st_b = pair < npairs;
     u.shifted = false;
-    if (!u.st_a) {
-      u.f0 = 2 * pair0;
+    if (!u.st_a) {  // this half has no pair of its own: it repeats valid frames and stores nothing
+      u.f0 = 2 * pair0 + 1 < p.nframes ? 2 * pair0 : 2 * pair0 - 1;
     } else if (u.f0 + 1 >= p.nframes) {
       u.f0 -= 1;
       u.st_a = false;
@@ -283,12 +290,32 @@ __global__ __launch_bounds__(kMaxWaves * 64, 4) void stft1024_u8_kernel(StftPara
     }
   };
   Unit cur = locate(0);
-  if (cur.active) fetch(cur);
+  fetch(cur);
+  uint4 fq[2] = {};  // RGBA: this lane's slot reads for the quarter that the iteration writes out
   // RGBA: one more round than there are frames for, which only writes out the last slot
   for (uint64_t it = 0; !RGBA || it < (rounds + 1) * kTileIters; ++it) {
     if (!RGBA && !cur.active) break;
     uint32_t* slot = slots + ((it / kTileIters) & 1) * (kRoundBytes / 4);
     const Unit nxt = locate(it + 1);
+    // RGBA: a quarter of the previous round, from the other slot.  Its stores are issued right after
+    // the iteration has consumed its sample loads, when nothing else is in flight, and then have the
+    // whole iteration to drain before the next wait on the memory counter.
+    auto flush_prev = [&]() {
+      if constexpr (RGBA) {
+        const uint64_t round = it / kTileIters;
+        if (round > 0) {
+          const uint64_t frame0 = ((round - 1) * gridDim.x + vb) * kRoundFrames;
+          if (frame0 < p.nframes) flush_quarter_store(p, fq, lut_lds, frame0, (int)(it % kTileIters), wave, lane);
+        }
+      }
+    };
+    if constexpr (RGBA) {
+      // (the empty asm is a use of the sample registers: the wait for their loads lands here, before
+      // the stores, and not behind them)
+#pragma unroll
+      for (int a = 0; a < kRaw; ++a) asm volatile("" : "+v"(raw[a]));
+      flush_prev();
+    }
     do {
     if (!cur.active) break;
     const uint64_t f0 = cur.f0;
@@ -401,32 +428,21 @@ __global__ __launch_bounds__(kMaxWaves * 64, 4) void stft1024_u8_kernel(StftPara
         const auto sb = __builtin_amdgcn_permlane32_swap(wb2[0], wb2[1], false, false);
         const int kq = 64 * P + l + 32 * h;               // reader wavefront kq >> 3, its quad kq & 7
         const int fg = 4 * wave + (int)(it % kTileIters);  // frame group of the round
-#if SONO_EXP == 2
-        if (sa[0] == 0x12345678u)
-#endif
         if (4 * kq >= (int)p.bin_lo && 4 * kq < (int)p.bin_hi)
           reinterpret_cast<uint4*>(slot)[((kq >> 3) * 64 + fg) * 8 + (kq & 7)] = make_uint4(sa[0], sb[0], sa[1], sb[1]);
       }
       wave_sync();  // the buffer is rewritten by the next half / the next iteration's transpose
     }
     } while (0);
-    if (nxt.active) {
-      fetch(nxt);
-    } else {  // (a constant, so that this iteration's samples do not stay live as the fall-through value)
-#pragma unroll
-      for (int a = 0; a < kRaw; ++a) raw[a] = 0.0f;
-    }
+    fetch(nxt);  // unconditional (an inactive unit points at frame 0): no stale values carried round the loop
     cur = nxt;
     if constexpr (RGBA) {
-      const uint64_t round = it / kTileIters;
-      if (round > 0) {  // a quarter of the previous round, from the other slot
-        const uint64_t frame0 = ((round - 1) * gridDim.x + vb) * kRoundFrames;
-        if (frame0 < p.nframes)
-          flush_quarter(p, slots + ((round - 1) & 1) * (kRoundBytes / 4), lut_lds, frame0, (int)(it % kTileIters), wave, lane);
-      }
       // End of a round: this round's slot is complete (and visible: one CU, one L1), and every
       // wavefront is done reading the other slot, which the next round overwrites.
       if (it % kTileIters == kTileIters - 1) __syncthreads();
+      const uint64_t nround = (it + 1) / kTileIters;
+      if (nround > 0 && nround <= rounds)
+        flush_quarter_load(fq, slots + ((nround - 1) & 1) * (kRoundBytes / 4), (int)((it + 1) % kTileIters), wave, lane);
     }
   }
 }
