@@ -28,6 +28,7 @@ struct sono_ctx {
   uint32_t* d_lut = nullptr;  // 256 packed pixels
   void* d_fast = nullptr;     // twiddle matrix of the fast kernel (accurate twiddles only)
   bool have_lut = false;
+  bool host_twiddles = false;  // sono_set_tables replaced the twiddle table
   // host copies (sono_set_tables may replace part of them)
   std::vector<float> h_window;
   std::vector<double> h_cos, h_sin;
@@ -257,6 +258,7 @@ int sono_set_tables(sono_ctx* c, const float* window, const double* tw_cos, cons
   if (tw_cos) {
     std::memcpy(c->h_cos.data(), tw_cos, sizeof(double) * (n - 1));
     std::memcpy(c->h_sin.data(), tw_sin, sizeof(double) * (n - 1));
+    c->host_twiddles = true;
   }
   return upload_tables(c);
 }
@@ -279,9 +281,16 @@ uint64_t sono_out_bytes(const sono_ctx* c, uint64_t L) {
 
 static uint64_t in_bytes(const sono_ctx* c, uint64_t L) { return L * (c->cfg.in_kind == SONO_IN_I16 ? 2 : 4); }
 
-static bool fast_eligible(const sono_ctx* c) {
-  return c->cfg.arith == SONO_ARITH_FAST_F32 && c->cfg.twiddle_mode == SONO_TW_ACCURATE;
+// Which flavour of the fast 1024-point kernel serves this context (StftParams::fast_mode).
+static uint32_t fast_mode_of(const sono_ctx* c) {
+  if (c->cfg.arith != SONO_ARITH_FAST_F32 || c->cfg.fft_n != 1024) return 0;
+  if (c->cfg.twiddle_mode == SONO_TW_ACCURATE && !c->host_twiddles) return c->d_fast ? 1 : 0;
+  // table twiddles: the kernel folds the first butterfly of every stage, so that factor must be 1
+  for (uint32_t T = 1; T < c->cfg.fft_n; T <<= 1)
+    if (c->h_cos[T - 1] != 1.0 || c->h_sin[T - 1] != 0.0) return 0;
+  return 2;
 }
+static bool fast_eligible(const sono_ctx* c) { return fast_mode_of(c) != 0; }
 
 int sono_stft_async(sono_ctx* c, const void* pcm, uint64_t L, void* out, uint64_t cap) {
   if (!c) return SONO_ERR_ARG;
@@ -311,6 +320,7 @@ int sono_stft_async(sono_ctx* c, const void* pcm, uint64_t L, void* out, uint64_
   p.lut = c->have_lut ? c->d_lut : nullptr;
   p.out = out;
   p.fast_table = c->d_fast;
+  p.fast_mode = fast_mode_of(c);
   p.tile_scratch = nullptr;
   p.scale_mode = c->cfg.scale_mode;
   p.out_kind = c->cfg.out_kind;

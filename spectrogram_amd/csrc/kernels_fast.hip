@@ -97,6 +97,40 @@ __device__ __forceinline__ void fft32(float (&re)[32], float (&im)[32]) {
   }
 }
 
+// The same 32-point network with twiddles from a table (the plugin's recurrence factors or a host
+// table: not exact roots of unity, so every butterfly must use the very factor the reference uses).
+// tw(half, j) returns the factor (cos, sin) of the butterfly at position j of a stage with half size
+// `half` (sin < 0 for the forward transform, spectrogram.esm.js:176-190).  FIRST: these are the first
+// five stages of the 1024-point transform, where j == 0 is the factor (1, 0) exactly in every table
+// this kernel accepts (checked on the host); in the last five stages every butterfly has a factor.
+template <bool FIRST, class TwFn>
+__device__ __forceinline__ void fft32_table(float (&re)[32], float (&im)[32], TwFn tw) {
+#pragma unroll
+  for (int s = 0; s < 5; ++s) {
+    const int half = 1 << s;
+#pragma unroll
+    for (int j = 0; j < half; ++j) {
+      float2 w = make_float2(1.0f, 0.0f);
+      if (!FIRST || j != 0) w = tw(half, j);
+#pragma unroll
+      for (int g = 0; g < 32; g += 2 * half) {
+        const int i0 = g + j, i1 = i0 + half;
+        const float ar = re[i0], ai = im[i0], br = re[i1], bi = im[i1];
+        if (FIRST && j == 0) {
+          re[i0] = ar + br; im[i0] = ai + bi;
+          re[i1] = ar - br; im[i1] = ai - bi;
+        } else {  // o1 = a + w*b, o2 = a - w*b = 2a - o1
+          const float o1r = __builtin_fmaf(-w.y, bi, __builtin_fmaf(w.x, br, ar));
+          const float o1i = __builtin_fmaf(w.y, br, __builtin_fmaf(w.x, bi, ai));
+          re[i0] = o1r; im[i0] = o1i;
+          re[i1] = __builtin_fmaf(2.0f, ar, -o1r);
+          im[i1] = __builtin_fmaf(2.0f, ai, -o1i);
+        }
+      }
+    }
+  }
+}
+
 // Orders this wavefront's LDS traffic for the compiler.  The hardware executes one wavefront's LDS
 // instructions in issue order, so data written by one lane is visible to a later read by another
 // lane of the same wavefront without a workgroup barrier.
@@ -200,17 +234,36 @@ __device__ __forceinline__ void flush_quarter_store(const StftParams& p, const u
 // the other.  The two half-wavefronts first swap registers (v_permlane32_swap) so that a lane holds
 // the same four bins of all four frames of the iteration: one 16-byte scratch store per lane and
 // epilogue half, 128 bytes (one line) per eight lanes.
-template <bool PLUGIN, typename In, int HOP32, bool RGBA>
+//
+// OUT: kOutU8 / kOutRgba / kOutFeatures (per-frame spectral peak: strict-> first-wins argmax of |X|^2
+// over the band and that bin's colour index; 8 bytes per frame).
+// TABLE: twiddles are the context's per-stage table (flat layout, stage with half size T at [T-1, 2T-1))
+// instead of exact roots of unity: the first pass reads its 31 factors as wave-uniform scalars, the
+// second pass reads factor 32*(g mod t) + lane of stage T = 32t from a [31][32] copy in LDS, and there
+// is no twiddle multiplication between the passes (it is part of those factors).
+constexpr int kOutU8 = 0, kOutRgba = 1, kOutFeatures = 2;
+template <bool PLUGIN, typename In, int HOP32, int OUT, bool TABLE>
 __global__ __launch_bounds__(kMaxWaves * 64, 4) void stft1024_u8_kernel(StftParams p, FastScale fs,
                                                                         const float2* __restrict__ tw_table,
                                                                         uint8_t* __restrict__ tiles) {
+  constexpr bool RGBA = OUT == kOutRgba, FEAT = OUT == kOutFeatures;
   constexpr int kThreads = kMaxWaves * 64, kWaves = kMaxWaves;
   constexpr int kTileIters = RGBA ? kTileFrames / 4 : 1;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float2* tw_lds = reinterpret_cast<float2*>(smem);
   float* win_lds = reinterpret_cast<float*>(smem + kTwBytes);
+  const float2* __restrict__ tw_flat = reinterpret_cast<const float2*>(p.twiddles);
   for (int i = threadIdx.x; i < 1024; i += kThreads) {
-    tw_lds[i] = tw_table[i];
+    if constexpr (TABLE) {
+      // row r = half - 1 + j of the second pass: stage T = 32*half, factor 32*j + lane
+      const int r = i >> 5, lane_p = i & 31;
+      if (r < 31) {
+        const int half = 1 << (31 - __builtin_clz(r + 1)), j = r + 1 - half;
+        tw_lds[i] = tw_flat[32 * half - 1 + 32 * j + lane_p];
+      }
+    } else {
+      tw_lds[i] = tw_table[i];
+    }
     win_lds[(i & 31) * kPlaneStride + (i >> 5)] = p.window[i];  // sample n = 32a + l at [l][a]
   }
   uint32_t* lut_lds = reinterpret_cast<uint32_t*>(smem + lds_bytes(kMaxWaves));
@@ -335,17 +388,21 @@ __global__ __launch_bounds__(kMaxWaves * 64, 4) void stft1024_u8_kernel(StftPara
         im[brev5(a)] = raw[a + (HOP32 > 0 ? HOP32 : 32)] * win[a];
       }
     }
-    fft32(re, im);  // Y_l[k1]
-
-    // twiddle W_1024^(l*k1), then transpose lane l, register k1 -> lane k1, register l; the real and
-    // the imaginary plane go through the same LDS buffer one after the other
+    // first pass; then (exact roots only) the twiddle W_1024^(l*k1); then transpose lane l, register
+    // k1 -> lane k1, register l; the real and the imaginary plane go through the same LDS buffer one
+    // after the other
+    if constexpr (TABLE) {
+      fft32_table<true>(re, im, [&](int half, int j) { return tw_flat[half - 1 + j]; });  // stages T = 1..16, wave-uniform
+    } else {
+      fft32(re, im);  // Y_l[k1]
 #pragma unroll
-    for (int k1 = 1; k1 < 32; ++k1) {
-      const float2 t = tw_lds[k1 * 32 + l];
-      const float ur = __builtin_fmaf(re[k1], t.x, -im[k1] * t.y);
-      const float ui = __builtin_fmaf(re[k1], t.y, im[k1] * t.x);
-      re[k1] = ur;
-      im[k1] = ui;
+      for (int k1 = 1; k1 < 32; ++k1) {
+        const float2 t = tw_lds[k1 * 32 + l];
+        const float ur = __builtin_fmaf(re[k1], t.x, -im[k1] * t.y);
+        const float ui = __builtin_fmaf(re[k1], t.y, im[k1] * t.x);
+        re[k1] = ur;
+        im[k1] = ui;
+      }
     }
 #pragma unroll
     for (int k1 = 0; k1 < 32; ++k1) plane[k1 * kPlaneStride + l] = re[k1];
@@ -371,7 +428,11 @@ __global__ __launch_bounds__(kMaxWaves * 64, 4) void stft1024_u8_kernel(StftPara
       }
     }
     wave_sync();
-    fft32(re, im);  // X[l + 32*k2]
+    if constexpr (TABLE) {
+      fft32_table<false>(re, im, [&](int half, int j) { return tw_lds[(half - 1 + j) * 32 + l]; });  // stages T = 32..512
+    } else {
+      fft32(re, im);  // X[l + 32*k2]
+    }
 
     // Epilogue in two halves of 256 bins.  For half P the registers k2 in [8P, 8P+8) hold Z[k] for
     // k = 256P .. 256P+255 and the registers k2 in [24-8P, 32-8P) hold the partners Z[N-k]; both are
@@ -379,6 +440,8 @@ __global__ __launch_bounds__(kMaxWaves * 64, 4) void stft1024_u8_kernel(StftPara
     // aligned 16-byte reads each.  Lane 0's registers sit one row off (k1 = 0), so it also supplies
     // mbuf[0] (Z[N - 256P] = Z[0] or Z[768]).
     const uint64_t row_a = (p.col0 + f0) * p.out_bins, row_b = row_a + p.out_bins;
+    float best_a = -1.0f, best_b = -1.0f;  // FEAT: this lane's largest |X|^2 so far and its bin
+    int kbest_a = (int)p.bin_lo, kbest_b = (int)p.bin_lo;
 #pragma unroll
     for (int P = 0; P < 2; ++P) {
 #pragma unroll
@@ -400,12 +463,20 @@ __global__ __launch_bounds__(kMaxWaves * 64, 4) void stft1024_u8_kernel(StftPara
         const float4 q01 = *reinterpret_cast<const float4*>(mbuf + idx);
         const float4 q23 = *reinterpret_cast<const float4*>(mbuf + idx + 2);
         uint32_t wa = 0, wb = 0;
+        const bool in_band = k >= (int)p.bin_lo && k < (int)p.bin_hi;
 #define SONO_BIN(B, ZR, ZI, PR, PI)                                          \
   {                                                                          \
     const float ar = (ZR) + (PR), ai = (ZI) - (PI);                          \
     const float br = (ZI) + (PI), bi = (PR) - (ZR);                          \
-    wa = put_index<PLUGIN, B>(__builtin_fmaf(ar, ar, ai * ai), fs, wa);      \
-    wb = put_index<PLUGIN, B>(__builtin_fmaf(br, br, bi * bi), fs, wb);      \
+    const float ma = __builtin_fmaf(ar, ar, ai * ai);                        \
+    const float mb = __builtin_fmaf(br, br, bi * bi);                        \
+    if constexpr (FEAT) { /* a lane visits its bins in ascending order */    \
+      if (in_band && ma > best_a) { best_a = ma; kbest_a = k + B; }          \
+      if (in_band && mb > best_b) { best_b = mb; kbest_b = k + B; }          \
+    } else {                                                                 \
+      wa = put_index<PLUGIN, B>(ma, fs, wa);                                 \
+      wb = put_index<PLUGIN, B>(mb, fs, wb);                                 \
+    }                                                                        \
   }
         SONO_BIN(0, z01.x, z01.y, q01.x, q01.y)
         SONO_BIN(1, z01.z, z01.w, q01.z, q01.w)
@@ -415,7 +486,7 @@ __global__ __launch_bounds__(kMaxWaves * 64, 4) void stft1024_u8_kernel(StftPara
         if constexpr (RGBA) {
           wa2[g] = shifted ? wb : wa;  // an odd last frame was computed as B: it belongs in the A slot
           wb2[g] = wb;
-        } else if (k >= (int)p.bin_lo && k < (int)p.bin_hi) {
+        } else if (!FEAT && in_band) {
           const uint32_t col = k - p.out_bin0;
           if (st_a) *reinterpret_cast<uint32_t*>(out + row_a + col) = wa;
           if (st_b) *reinterpret_cast<uint32_t*>(out + row_b + col) = wb;
@@ -432,6 +503,31 @@ __global__ __launch_bounds__(kMaxWaves * 64, 4) void stft1024_u8_kernel(StftPara
           reinterpret_cast<uint4*>(slot)[((kq >> 3) * 64 + fg) * 8 + (kq & 7)] = make_uint4(sa[0], sb[0], sa[1], sb[1]);
       }
       wave_sync();  // the buffer is rewritten by the next half / the next iteration's transpose
+    }
+    if constexpr (FEAT) {
+      // reduce over the 32 lanes of the half-wavefront: larger |X|^2 wins, equal values go to the lower bin
+#pragma unroll
+      for (int m = 1; m < 32; m <<= 1) {
+        const float oa = __shfl_xor(best_a, m, 64), ob = __shfl_xor(best_b, m, 64);
+        const int ka = __shfl_xor(kbest_a, m, 64), kb = __shfl_xor(kbest_b, m, 64);
+        if (oa > best_a || (oa == best_a && ka < kbest_a)) { best_a = oa; kbest_a = ka; }
+        if (ob > best_b || (ob == best_b && kb < kbest_b)) { best_b = ob; kbest_b = kb; }
+      }
+      if (l == 0) {
+        sono_frame_feature* ft = reinterpret_cast<sono_frame_feature*>(p.out) + (p.col0 + f0);
+        if (st_a) {
+          sono_frame_feature r{};
+          r.peak_bin = kbest_a;
+          r.peak_idx = (uint8_t)put_index<PLUGIN, 0>(best_a, fs, 0);
+          ft[0] = r;
+        }
+        if (st_b) {
+          sono_frame_feature r{};
+          r.peak_bin = kbest_b;
+          r.peak_idx = (uint8_t)put_index<PLUGIN, 0>(best_b, fs, 0);
+          ft[1] = r;
+        }
+      }
     }
     } while (0);
     fetch(nxt);  // unconditional (an inactive unit points at frame 0): no stale values carried round the loop
@@ -461,17 +557,30 @@ void build_fast_table_1024(std::vector<float>& t) {
     }
 }
 
-bool fast_u8_available(const StftParams& p) {
-  if (p.n != 1024 || !p.fast_table) return false;
-  if ((p.bin_lo & 3) || (p.bin_hi & 3) || (p.out_bins & 3) || (p.out_bin0 & 3)) return false;
+// fast_mode: 0 = no fast kernel for this context, 1 = exact roots of unity (fast_table holds the
+// W_1024^(l*k1) matrix), 2 = the context's per-stage twiddle table (p.twiddles, float2).
+static bool fast_base_available(const StftParams& p) {
+  if (p.n != 1024 || p.fast_mode == 0) return false;
+  if (p.fast_mode == 1 && !p.fast_table) return false;
+  if (p.fast_mode == 2 && !p.twiddles) return false;
   if (p.nframes < 16) return false;  // a handful of frames (e.g. the worker's wrapped last frame): general kernel
   return true;
 }
 
+bool fast_u8_available(const StftParams& p) {
+  if (!fast_base_available(p)) return false;
+  if ((p.bin_lo & 3) || (p.bin_hi & 3) || (p.out_bins & 3) || (p.out_bin0 & 3)) return false;
+  return true;
+}
+
+bool fast_features_available(const StftParams& p) {
+  return fast_base_available(p) && !(p.bin_lo & 3) && !(p.bin_hi & 3) && p.bin_lo < p.bin_hi;
+}
+
 // The fused image output needs whole 16-bin groups, the flipped full-height row mapping and store
-// offsets (up to 48 image rows) that fit 32 bits.
+// offsets (a few image rows) that fit 32 bits.
 bool fast_rgba_available(const StftParams& p) {
-  if (p.n != 1024 || !p.fast_table || p.nframes < 16) return false;
+  if (!fast_base_available(p)) return false;
   if ((p.bin_lo & 15) || (p.bin_hi & 15) || p.bin_lo >= p.bin_hi) return false;
   if (p.row_of_bin0 != (int32_t)p.bin_hi - 1) return false;
   if (p.width == 0 || p.width > ((uint64_t)1 << 24) || !p.lut) return false;
@@ -490,9 +599,11 @@ uint64_t fast_rgba_scratch_bytes() { return (uint64_t)cu_count() * 2 * fast1024:
 
 int launch_stft_fast(const StftParams& p, void* stream_v) {
   using namespace fast1024;
-  const bool rgba = p.out_kind == SONO_OUT_RGBA8;
+  const bool rgba = p.out_kind == SONO_OUT_RGBA8, feat = p.out_kind == SONO_OUT_FEATURES;
   if (rgba) {
     if (!fast_rgba_available(p) || !p.tile_scratch) return 1;
+  } else if (feat) {
+    if (!fast_features_available(p)) return 1;
   } else {
     if (p.out_kind != SONO_OUT_U8_INDEX || !fast_u8_available(p)) return 1;
   }
@@ -503,7 +614,7 @@ int launch_stft_fast(const StftParams& p, void* stream_v) {
   fs.b -= 2.0f * fs.a;
   fs.db_off -= 2.0f * 3.0102999566f;
   const uint64_t npairs = (p.nframes + 1) / 2;
-  // one wavefront handles 2 pairs per iteration (u8) or one 16-frame tile per 4 iterations (RGBA)
+  // one wavefront handles 2 pairs per iteration, or (RGBA) one 16-frame tile per 4 iterations
   const uint64_t per_wg = rgba ? (uint64_t)kRoundFrames / 2 : (uint64_t)kMaxWaves * 2;
   const uint64_t need = (npairs + per_wg - 1) / per_wg;
   const int cus = cu_count();
@@ -511,17 +622,24 @@ int launch_stft_fast(const StftParams& p, void* stream_v) {
   const float2* table = reinterpret_cast<const float2*>(p.fast_table);
   uint8_t* tiles = reinterpret_cast<uint8_t*>(p.tile_scratch);
   const int lds_total = lds_bytes(kMaxWaves) + (rgba ? kLutBytes : 0);
-#define SONO_LAUNCH_R(PLUGIN, In, H, R)                                                                     \
+  const bool tab = p.fast_mode == 2;
+#define SONO_LAUNCH_T(PLUGIN, In, H, O, T)                                                                  \
   do {                                                                                                      \
-    auto kern = stft1024_u8_kernel<PLUGIN, In, H, R>;                                                       \
+    auto kern = stft1024_u8_kernel<PLUGIN, In, H, O, T>;                                                    \
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, \
                             lds_total) != hipSuccess)                                                       \
       return SONO_ERR_DEVICE;                                                                               \
     hipLaunchKernelGGL(kern, dim3(grid), dim3(kMaxWaves * 64), lds_total, stream, p, fs, table, tiles);     \
   } while (0)
+#define SONO_LAUNCH_O(PLUGIN, In, H, O)                                                                     \
+  do {                                                                                                      \
+    if (tab) SONO_LAUNCH_T(PLUGIN, In, H, O, true); else SONO_LAUNCH_T(PLUGIN, In, H, O, false);            \
+  } while (0)
 #define SONO_LAUNCH_H(PLUGIN, In, H)                                                                        \
   do {                                                                                                      \
-    if (rgba) SONO_LAUNCH_R(PLUGIN, In, H, true); else SONO_LAUNCH_R(PLUGIN, In, H, false);                 \
+    if (rgba) SONO_LAUNCH_O(PLUGIN, In, H, kOutRgba);                                                       \
+    else if (feat) SONO_LAUNCH_O(PLUGIN, In, H, kOutFeatures);                                              \
+    else SONO_LAUNCH_O(PLUGIN, In, H, kOutU8);                                                              \
   } while (0)
 #define SONO_LAUNCH(PLUGIN, In)                                                                             \
   do {                                                                                                      \
@@ -537,7 +655,8 @@ int launch_stft_fast(const StftParams& p, void* stream_v) {
   }
 #undef SONO_LAUNCH
 #undef SONO_LAUNCH_H
-#undef SONO_LAUNCH_R
+#undef SONO_LAUNCH_O
+#undef SONO_LAUNCH_T
   return hipGetLastError() == hipSuccess ? SONO_OK : SONO_ERR_DEVICE;
 }
 

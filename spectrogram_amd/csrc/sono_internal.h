@@ -35,6 +35,7 @@ struct StftParams {
   const uint32_t* lut;    // device, 256 packed RGBA (little endian r | g<<8 | b<<16 | a<<24), or nullptr = grey
   void* out;              // device
   const void* fast_table; // device: per-size twiddle matrix of the fast kernels, or nullptr
+  uint32_t fast_mode;     // 0: no fast kernel; 1: exact roots of unity (fast_table); 2: the per-stage table `twiddles`
   void* tile_scratch;     // device: fast_rgba_scratch_bytes() of scratch for the fused RGBA output, or nullptr
   uint32_t scale_mode, out_kind, in_kind;
   double gain_db, range_db;
@@ -54,6 +55,7 @@ int launch_colorize(const uint8_t* frames, uint64_t ncols, uint32_t bins, uint32
 bool fast_u8_available(const StftParams& p);
 // True when launch_stft_fast can write the RGBA image itself (given tile_scratch).
 bool fast_rgba_available(const StftParams& p);
+bool fast_features_available(const StftParams& p);
 uint64_t fast_rgba_scratch_bytes();
 int launch_frame_peaks(const uint8_t* idx, uint64_t frames, uint32_t bins, int32_t* peak_bin, uint8_t* peak_idx,
                        void* hip_stream);

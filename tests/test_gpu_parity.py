@@ -376,3 +376,72 @@ def test_feature_pass_to_autoid_data():
         assert d["startFreq"] > d["endFreq"] and 30 <= d["lowestFreq"] < d["highestFreq"] <= 90
         assert 2.0 <= d["duration"] <= 8.0
         assert isinstance(auto_id_hk(d, G.manifest["species_rules"]), str)
+
+
+# ------------------------------------------------------------------ fast 1024-point kernel: every flavour
+@pytest.mark.gpu
+@pytest.mark.parametrize("hop", [256, 512, 100])
+@pytest.mark.parametrize("in_kind", ["f32", "i16"])
+def test_fast_table_twiddle_kernel_against_oracle(hop, in_kind):
+    """Plugin semantics with the recurrence twiddles run in the fast kernel's table flavour: uint8 indices
+    within 1 LSB (cyclic at the 256 -> 0 wrap) of the checker, for the three sample-load variants and
+    both input types; band-cropped RGBA and the per-frame peaks come out of the same kernel."""
+    rng = np.random.default_rng(100 + hop)
+    L = 1024 + hop * 1537 + 7
+    x = (rng.standard_normal(L) * 0.15).astype(np.float32)
+    x[5000:90000] += (0.5 * np.sin(np.arange(85000) * 0.7 + 1e-5 * np.arange(85000) ** 2)).astype(np.float32)
+    kw = {}
+    if in_kind == "i16":
+        q = np.round(np.clip(x, -1, 1) * 32767).astype(np.int16)
+        x = (q.astype(np.float32) / 32768.0).astype(np.float32)
+        kw["in_kind"] = F.IN_I16
+    src = q if in_kind == "i16" else x
+    ref, mags, _, _ = oracle.plugin_get_frequencies(x, 1024, 1024 - hop, want_mags=True)
+    with plugin_engine(1024, hop, F.ARITH_FAST_F32, **kw) as eng:
+        got = eng.stft(src)
+    d = cyc_diff(got, ref)
+    assert got.shape == ref.shape and d.max() <= 1 and (d != 0).mean() < 0.02        # <= 1 LSB
+    # band crop (16-bin groups) + colour map through the fused image writer
+    lut = (np.arange(1024, dtype=np.uint32) * 7 % 256).astype(np.uint8)
+    with plugin_engine(1024, hop, F.ARITH_FAST_F32, out_kind=F.OUT_RGBA8, bin_lo=48, bin_hi=320, **kw) as eng:
+        eng.set_colormap(lut)
+        img = eng.stft(src)
+    want = lut.reshape(256, 4)[got[:, 48:320].T[::-1]]
+    assert img.shape == want.shape and np.array_equal(img, want)                    # same kernel, same indices
+    # per-frame peaks: integer indices equal the checker's unless the two largest bins are a near-tie
+    with plugin_engine(1024, hop, F.ARITH_FAST_F32, out_kind=F.OUT_FEATURES, bin_lo=48, bin_hi=320, **kw) as eng:
+        ft = eng.stft(src)
+    refp = oracle.frame_peaks_f32(mags, 48, 320)
+    diff = np.nonzero(ft["peak_bin"] != refp)[0]
+    for f in diff:
+        a, b = mags[f, refp[f]], mags[f, ft["peak_bin"][f]]
+        assert abs(a - b) <= 2e-5 * a
+    assert len(diff) <= max(2, len(refp) // 500)
+    same = ft["peak_bin"] == refp
+    assert cyc_diff(ft["peak_idx"][same], ref[np.arange(len(refp)), refp][same]).max() <= 1
+
+
+@pytest.mark.gpu
+def test_fast_worker_features_and_host_table():
+    x = G.signal("bat")
+    hop = E.worker_hop(1024, 75)
+    _, width, frames = oracle.worker_geometry(len(x), 1024, 75)
+    wm, wi = oracle.worker_magnitudes(x, 1024, hop, frames)
+    ref = oracle.frame_peaks_f32(wm)
+    with worker_engine(1024, hop, F.ARITH_FAST_F32, out_kind=F.OUT_FEATURES) as eng:
+        ft = eng.stft(x)
+    assert len(ft) == frames
+    diff = np.nonzero(ft["peak_bin"] != ref)[0]
+    for f in diff:
+        a, b = wm[f, ref[f]], wm[f, ft["peak_bin"][f]]
+        assert abs(a - b) <= 2e-5 * a
+    assert len(diff) <= 1
+    same = ft["peak_bin"] == ref
+    assert np.abs(ft["peak_idx"][same].astype(int) - wi[np.arange(frames), ref][same]).max() <= 1
+    # a host-supplied twiddle table (here: the exact roots) goes through the table flavour and agrees
+    c, s = E.twiddle_table(F.TW_ACCURATE, 1024)
+    with worker_engine(1024, hop, F.ARITH_FAST_F32, out_kind=F.OUT_U8_INDEX) as eng:
+        a = eng.stft(x)
+        eng.set_tables(None, c, s)
+        b = eng.stft(x)
+    assert np.abs(a.astype(int) - b.astype(int)).max() <= 1

@@ -1,5 +1,5 @@
 // Native benchmark / profiling host for libsonospec.so: no Python, no PyTorch, just the C ABI.
-//   sono_bench [seconds=600] [steps=5] [out=u8|rgba] [fft=1024] [hop=256]
+//   sono_bench [seconds=600] [steps=5] [out=u8|rgba|feat] [fft=1024] [hop=256] [path=worker|plugin] [bin_lo bin_hi]
 // Generates a seeded synthetic recording on the host, copies it to the GPU once, runs the worker-path
 // transform `steps` times on device-resident buffers and prints Msamples/s from HIP-event timing.
 #include <cmath>
@@ -15,6 +15,8 @@ int main(int argc, char** argv) {
   const int seconds = argc > 1 ? atoi(argv[1]) : 600;
   const int steps = argc > 2 ? atoi(argv[2]) : 5;
   const bool rgba = argc > 3 && !strcmp(argv[3], "rgba");
+  const bool feat = argc > 3 && !strcmp(argv[3], "feat");
+  const bool plugin = argc > 6 && !strcmp(argv[6], "plugin");
   const uint32_t fft = argc > 4 ? (uint32_t)atoi(argv[4]) : 1024;
   const uint32_t hop = argc > 5 ? (uint32_t)atoi(argv[5]) : 256;
   const uint64_t L = (uint64_t)seconds * 384000ull;
@@ -31,12 +33,16 @@ int main(int argc, char** argv) {
   memset(&cfg, 0, sizeof cfg);
   cfg.fft_n = fft;
   cfg.hop = hop;
-  cfg.window_id = SONO_WIN_WORKER_HANN;
-  cfg.scale_mode = SONO_SCALE_WORKER_LOG5;
-  cfg.frame_rule = SONO_FRAMES_WORKER_COMPAT;
-  cfg.twiddle_mode = SONO_TW_ACCURATE;
+  cfg.window_id = plugin ? SONO_WIN_HANN : SONO_WIN_WORKER_HANN;
+  cfg.scale_mode = plugin ? SONO_SCALE_PLUGIN_DB : SONO_SCALE_WORKER_LOG5;
+  cfg.frame_rule = plugin ? SONO_FRAMES_PLUGIN_STRICT : SONO_FRAMES_WORKER_COMPAT;
+  cfg.twiddle_mode = plugin ? SONO_TW_PLUGIN_RECURRENCE : SONO_TW_ACCURATE;
   cfg.arith = SONO_ARITH_FAST_F32;
-  cfg.out_kind = rgba ? SONO_OUT_RGBA8 : SONO_OUT_U8_INDEX;
+  cfg.out_kind = rgba ? SONO_OUT_RGBA8 : feat ? SONO_OUT_FEATURES : SONO_OUT_U8_INDEX;
+  if (argc > 8) {
+    cfg.bin_lo = (uint32_t)atoi(argv[7]);
+    cfg.bin_hi = (uint32_t)atoi(argv[8]);
+  }
   cfg.in_kind = SONO_IN_F32;
   cfg.gain_db = 20;
   cfg.range_db = 80;
