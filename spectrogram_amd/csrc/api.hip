@@ -291,6 +291,13 @@ static uint32_t fast_mode_of(const sono_ctx* c) {
   return 2;
 }
 static bool fast_eligible(const sono_ctx* c) { return fast_mode_of(c) != 0; }
+// The 2048/4096-point kernel takes any twiddle table whose stages start with the factor (1, 0).
+static bool mw_eligible(const sono_ctx* c) {
+  if (c->cfg.arith != SONO_ARITH_FAST_F32 || (c->cfg.fft_n != 2048 && c->cfg.fft_n != 4096)) return false;
+  for (uint32_t T = 1; T < c->cfg.fft_n; T <<= 1)
+    if (c->h_cos[T - 1] != 1.0 || c->h_sin[T - 1] != 0.0) return false;
+  return true;
+}
 
 int sono_stft_async(sono_ctx* c, const void* pcm, uint64_t L, void* out, uint64_t cap) {
   if (!c) return SONO_ERR_ARG;
@@ -321,6 +328,7 @@ int sono_stft_async(sono_ctx* c, const void* pcm, uint64_t L, void* out, uint64_
   p.out = out;
   p.fast_table = c->d_fast;
   p.fast_mode = fast_mode_of(c);
+  p.mw_ok = mw_eligible(c) ? 1u : 0u;
   p.tile_scratch = nullptr;
   p.scale_mode = c->cfg.scale_mode;
   p.out_kind = c->cfg.out_kind;
@@ -346,7 +354,7 @@ int sono_stft_async(sono_ctx* c, const void* pcm, uint64_t L, void* out, uint64_
       if (r != SONO_OK) return fail(c, r, "kernel launch failed: %s", hipGetErrorString(hipGetLastError()));
       return SONO_OK;
     }
-    if (fast_eligible(c) && q.out_kind == SONO_OUT_RGBA8 && q.row_of_bin0 == (int32_t)q.bin_hi - 1) {
+    if ((fast_eligible(c) || q.mw_ok) && q.out_kind == SONO_OUT_RGBA8 && q.row_of_bin0 == (int32_t)q.bin_hi - 1) {
       // RGBA through the fast kernel: colour indices of a chunk of frames go to a context-owned
       // [frame][bin] buffer small enough to stay in the Infinity Cache, then a transposing LUT
       // kernel writes the chunk's image columns.
@@ -354,7 +362,7 @@ int sono_stft_async(sono_ctx* c, const void* pcm, uint64_t L, void* out, uint64_
       u.out_kind = SONO_OUT_U8_INDEX;
       u.out_bins = q.bin_hi - q.bin_lo;
       u.out_bin0 = q.bin_lo;
-      if (fast_u8_available(u)) {
+      if (fast_u8_available(u) || mw_u8_available(u)) {
         const uint64_t nb = u.out_bins;
         const uint64_t chunk = ((uint64_t)96 << 20) / nb / 64 * 64;   // frames per chunk (96 MiB of indices)
         int rc2 = ensure(c, &c->d_aux, &c->d_aux_bytes, (q.nframes < chunk ? q.nframes : chunk) * nb);
@@ -368,6 +376,8 @@ int sono_stft_async(sono_ctx* c, const void* pcm, uint64_t L, void* out, uint64_
             r = launch_stft_general(u, false, c->stream);
           } else {
             r = launch_stft_fast(u, c->stream);
+            if (r == 1) r = launch_stft_mw(u, c->stream);
+            if (r == 1) r = launch_stft_general(u, false, c->stream);
           }
           if (r != SONO_OK) return fail(c, r, "kernel launch failed: %s", hipGetErrorString(hipGetLastError()));
           r = launch_colorize((const uint8_t*)c->d_aux, u.nframes, (uint32_t)nb, 0, (uint32_t)nb, q.lut, (uint8_t*)q.out,
@@ -378,6 +388,7 @@ int sono_stft_async(sono_ctx* c, const void* pcm, uint64_t L, void* out, uint64_
       }
     }
     if (fast_eligible(c)) r = launch_stft_fast(q, c->stream);
+    if (r == 1 && q.mw_ok) r = launch_stft_mw(q, c->stream);
     if (r == 1) r = launch_stft_general(q, c->cfg.arith == SONO_ARITH_EXACT_F64, c->stream);
     if (r != SONO_OK) return fail(c, r, "kernel launch failed: %s", hipGetErrorString(hipGetLastError()));
     return SONO_OK;

@@ -1,0 +1,233 @@
+// Float32 STFT kernel for 2048- and 4096-point frames: one workgroup of N/16 threads (2 or 4
+// wavefronts) transforms one pair of real frames per iteration.
+//
+// Dataflow = the reference's radix-2 decimation in time (spectrogramWorker.js:206-253,
+// spectrogram.esm.js:166-200) with its per-stage twiddle TABLE (exact roots for the worker, the
+// recurrence factors for the plugin, or a host table), regrouped into three register passes:
+//   position k = [c | b | a]   (a: low 4 bits, b: next 4 bits, c: the top log2N - 8 bits)
+//   pass A: stages T = 1..8      over a, thread = (c, b)      factors uniform in the workgroup
+//   pass B: stages T = 16..128   over b, thread = (c, a)      factor 16*(b mod h) + a of stage 16h
+//   pass C: stages T = 256..N/2  over c, thread = (b, a)      factor 256*(c mod h) + 16b + a of stage 256h
+// so every butterfly multiplies by the very table entry the reference uses, and the data crosses LDS
+// twice instead of log2N times.  Thread t loads samples t + (N/16)*a' (coalesced) into register
+// a = rev4(a'), which is the bit-reversed load.  Two real frames share one complex transform
+// (z = w*(xA + i*xB); XA = (Z[k] + conj Z[N-k])/2, XB = (Z[k] - conj Z[N-k])/(2i)); a third LDS round
+// trip brings Z[k] and Z[N-k] together, and the epilogue fuses |X|^2 -> log2 -> quantiser -> packed uint8.
+//
+// LDS: two planes (re, im) of N floats, index k + (k >> 4) (one pad per 16: the strided accesses of
+// all three exchanges then fall on distinct banks), 34 KiB at N = 4096: four to five workgroups per CU,
+// each on its own barrier, so the CU always has wavefronts in a different phase.
+#include <hip/hip_runtime.h>
+
+#include "sono_device.h"
+#include "sono_internal.h"
+
+namespace sono {
+namespace mw {
+
+__host__ __device__ constexpr int rev4(int v) { return ((v & 1) << 3) | ((v & 2) << 1) | ((v & 4) >> 1) | ((v & 8) >> 3); }
+__device__ __forceinline__ int pad(int k) { return k + (k >> 4); }
+
+// R-point decimation-in-time network on registers in position order.  tw(half, j): factor (cos, sin) of
+// the butterfly (i, i + half), j = i mod half.  FIRST: j == 0 is the factor (1, 0) exactly.
+template <int R, bool FIRST, class TwFn>
+__device__ __forceinline__ void dit(float* re, float* im, TwFn tw) {
+#pragma unroll
+  for (int half = 1; half < R; half <<= 1) {
+#pragma unroll
+    for (int j = 0; j < half; ++j) {
+      float2 w = make_float2(1.0f, 0.0f);
+      if (!FIRST || j != 0) w = tw(half, j);
+#pragma unroll
+      for (int g = 0; g < R; g += 2 * half) {
+        const int i0 = g + j, i1 = i0 + half;
+        const float ar = re[i0], ai = im[i0], br = re[i1], bi = im[i1];
+        if (FIRST && j == 0) {
+          re[i0] = ar + br; im[i0] = ai + bi;
+          re[i1] = ar - br; im[i1] = ai - bi;
+        } else {  // o1 = a + w*b, o2 = a - w*b = 2a - o1
+          const float o1r = __builtin_fmaf(-w.y, bi, __builtin_fmaf(w.x, br, ar));
+          const float o1i = __builtin_fmaf(w.y, br, __builtin_fmaf(w.x, bi, ai));
+          re[i0] = o1r; im[i0] = o1i;
+          re[i1] = __builtin_fmaf(2.0f, ar, -o1r);
+          im[i1] = __builtin_fmaf(2.0f, ai, -o1i);
+        }
+      }
+    }
+  }
+}
+
+template <typename In>
+__device__ __forceinline__ float ld(const In* p, uint64_t i);
+template <>
+__device__ __forceinline__ float ld<float>(const float* p, uint64_t i) { return p[i]; }
+template <>
+__device__ __forceinline__ float ld<int16_t>(const int16_t* p, uint64_t i) { return (float)p[i] * (1.0f / 32768.0f); }
+
+template <bool PLUGIN, int BYTE>
+__device__ __forceinline__ uint32_t put_index(float msq, const FastScale& fs, uint32_t acc) {
+  if constexpr (PLUGIN) {
+    return acc | (fast_index(msq, fs) << (8 * BYTE));
+  } else {
+    const float t = __builtin_floorf(__builtin_fmaf(__log2f(msq), fs.a, fs.b));
+    return __builtin_amdgcn_cvt_pk_u8_f32(t, BYTE, acc);  // saturates to [0,255]; NaN -> 0
+  }
+}
+
+template <int LOG2N, bool PLUGIN, typename In>
+__global__ __launch_bounds__((1 << LOG2N) / 16, 4) void stft_mw_kernel(StftParams p, FastScale fs) {
+  constexpr int N = 1 << LOG2N, TN = N / 16, CB = LOG2N - 8, NC = 1 << CB, SETS = 16 / NC;
+  static_assert(CB >= 3 && CB <= 4, "2048 or 4096 points");
+  constexpr int kPlane = N + N / 16;
+  __shared__ float s_re[kPlane], s_im[kPlane];
+  const int t = threadIdx.x;
+  const float2* __restrict__ tw = reinterpret_cast<const float2*>(p.twiddles);
+  const In* __restrict__ x = reinterpret_cast<const In*>(p.pcm);
+  uint8_t* __restrict__ out = reinterpret_cast<uint8_t*>(p.out);
+
+  // pass A identity: t = rev4(b) * NC + rev_CB(c)
+  const int cA = (int)(__brev((unsigned)(t & (NC - 1))) >> (32 - CB)), bA = rev4(t >> CB);
+  const int kA = (cA * 16 + bA) * 16;  // position of register a = 0
+  // pass B identity: thread (c, a)
+  const int aB = t & 15, cB = t >> 4;
+  // pass C identity: thread value w = 16b + a (two of them, w and w + 128, at N = 2048)
+  float win[16];
+#pragma unroll
+  for (int a1 = 0; a1 < 16; ++a1) win[rev4(a1)] = p.window[t + TN * a1];
+
+  const uint64_t npairs = (p.nframes + 1) >> 1;
+  for (uint64_t pair = blockIdx.x; pair < npairs; pair += gridDim.x) {
+    uint64_t f0 = 2 * pair;
+    bool st_a = true;
+    if (f0 + 1 >= p.nframes) {  // odd last frame: computed as the second member of the pair before it
+      f0 -= 1;
+      st_a = false;
+    }
+    const In* xa = x + (p.frame0 + f0) * p.hop + t;
+    const In* xb = xa + p.hop;
+    float re[16], im[16];
+#pragma unroll
+    for (int a1 = 0; a1 < 16; ++a1) {
+      re[rev4(a1)] = ld<In>(xa, (uint64_t)TN * a1);
+      im[rev4(a1)] = ld<In>(xb, (uint64_t)TN * a1);
+    }
+#pragma unroll
+    for (int a = 0; a < 16; ++a) {
+      re[a] *= win[a];
+      im[a] *= win[a];
+    }
+    dit<16, true>(re, im, [&](int half, int j) { return tw[half - 1 + j]; });
+    // LDS cells as one base per thread plus compile-time offsets: pad(k) = k + (k >> 4)
+    const int cellA = kA + (kA >> 4);          // + a
+    const int cellB = cB * 272 + aB;           // + 17 * b
+#pragma unroll
+    for (int a = 0; a < 16; ++a) {
+      s_re[cellA + a] = re[a];
+      s_im[cellA + a] = im[a];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int b = 0; b < 16; ++b) {
+      re[b] = s_re[cellB + 17 * b];
+      im[b] = s_im[cellB + 17 * b];
+    }
+    // (the twiddle reads of passes B and C are invariant in this loop; the empty asm keeps them here, out
+    // of 60 registers that hoisted copies would hold)
+    int a_tw = aB;
+    asm volatile("" : "+v"(a_tw));
+    dit<16, false>(re, im, [&](int half, int j) { return tw[16 * half - 1 + 16 * j + a_tw]; });
+#pragma unroll
+    for (int b = 0; b < 16; ++b) {  // each thread rewrites exactly the cells it read
+      s_re[cellB + 17 * b] = re[b];
+      s_im[cellB + 17 * b] = im[b];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < SETS; ++s) {
+      const int w = t + TN * s;
+      const int cellC = w + (w >> 4);          // + 272 * c
+#pragma unroll
+      for (int c = 0; c < NC; ++c) {
+        re[s * NC + c] = s_re[cellC + 272 * c];
+        im[s * NC + c] = s_im[cellC + 272 * c];
+      }
+      int w_tw = w;
+      asm volatile("" : "+v"(w_tw));
+      dit<NC, false>(re + s * NC, im + s * NC, [&](int half, int j) { return tw[256 * half - 1 + 256 * j + w_tw]; });
+#pragma unroll
+      for (int c = 0; c < NC; ++c) {  // X[c*256 + w], again in the thread's own cells
+        s_re[cellC + 272 * c] = re[s * NC + c];
+        s_im[cellC + 272 * c] = im[s * NC + c];
+      }
+    }
+    __syncthreads();
+    // epilogue: thread handles the bin quads q = t, t + TN (N/8 quads per frame)
+    const uint64_t row_a = (p.col0 + f0) * p.out_bins, row_b = row_a + p.out_bins;
+#pragma unroll
+    for (int m = 0; m < (N / 8) / TN; ++m) {
+      const int k = 4 * (t + TN * m);
+      if (k >= (int)p.bin_lo && k < (int)p.bin_hi) {
+        uint32_t wa = 0, wb = 0;
+        const int cellZ = k + (k >> 4);  // + B (k is a multiple of 4)
+#define SONO_BIN(B)                                                            \
+  {                                                                            \
+    const int km = (N - k - B) & (N - 1);                                      \
+    const float zr = s_re[cellZ + B], zi = s_im[cellZ + B];                    \
+    const float pr = s_re[pad(km)], pi = s_im[pad(km)];                        \
+    const float ar = zr + pr, ai = zi - pi;                                    \
+    const float br = zi + pi, bi = pr - zr;                                    \
+    wa = put_index<PLUGIN, B>(__builtin_fmaf(ar, ar, ai * ai), fs, wa);        \
+    wb = put_index<PLUGIN, B>(__builtin_fmaf(br, br, bi * bi), fs, wb);        \
+  }
+        SONO_BIN(0) SONO_BIN(1) SONO_BIN(2) SONO_BIN(3)
+#undef SONO_BIN
+        const uint32_t col = k - p.out_bin0;
+        if (st_a) *reinterpret_cast<uint32_t*>(out + row_a + col) = wa;
+        *reinterpret_cast<uint32_t*>(out + row_b + col) = wb;
+      }
+    }
+    __syncthreads();  // the planes are rewritten by the next pair
+  }
+}
+
+}  // namespace mw
+
+bool mw_u8_available(const StftParams& p) {
+  if ((p.n != 2048 && p.n != 4096) || !p.mw_ok || !p.twiddles) return false;
+  if ((p.bin_lo & 3) || (p.bin_hi & 3) || (p.out_bins & 3) || (p.out_bin0 & 3)) return false;
+  if (p.nframes < 2) return false;
+  return true;
+}
+
+int launch_stft_mw(const StftParams& p, void* stream_v) {
+  using namespace mw;
+  if (p.out_kind != SONO_OUT_U8_INDEX || !mw_u8_available(p)) return 1;
+  if (reinterpret_cast<uintptr_t>(p.out) & 3) return 1;
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_v);
+  FastScale fs = make_fast_scale(p.scale_mode, p.n, p.gain_db, p.range_db);
+  fs.b -= 2.0f * fs.a;  // the pair separation leaves 2*X
+  fs.db_off -= 2.0f * 3.0102999566f;
+  const uint64_t npairs = (p.nframes + 1) / 2;
+  int dev = 0, cus = 256;
+  hipDeviceProp_t prop;
+  if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+    cus = prop.multiProcessorCount;
+  const uint64_t cap = (uint64_t)cus * (p.n == 4096 ? 4 : 8);
+  const uint32_t grid = (uint32_t)(npairs < cap ? npairs : cap);
+  const bool plugin = p.scale_mode == SONO_SCALE_PLUGIN_DB;
+#define SONO_MW(L2, PL, In) hipLaunchKernelGGL((stft_mw_kernel<L2, PL, In>), dim3(grid), dim3((1 << L2) / 16), 0, stream, p, fs)
+#define SONO_MW_IN(L2, PL)                                                 \
+  do {                                                                     \
+    if (p.in_kind == SONO_IN_I16) SONO_MW(L2, PL, int16_t); else SONO_MW(L2, PL, float); \
+  } while (0)
+  if (p.n == 4096) {
+    if (plugin) SONO_MW_IN(12, true); else SONO_MW_IN(12, false);
+  } else {
+    if (plugin) SONO_MW_IN(11, true); else SONO_MW_IN(11, false);
+  }
+#undef SONO_MW_IN
+#undef SONO_MW
+  return hipGetLastError() == hipSuccess ? SONO_OK : SONO_ERR_DEVICE;
+}
+
+}  // namespace sono

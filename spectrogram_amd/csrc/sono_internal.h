@@ -36,6 +36,7 @@ struct StftParams {
   void* out;              // device
   const void* fast_table; // device: per-size twiddle matrix of the fast kernels, or nullptr
   uint32_t fast_mode;     // 0: no fast kernel; 1: exact roots of unity (fast_table); 2: the per-stage table `twiddles`
+  uint32_t mw_ok;         // the twiddle table starts every stage with (1, 0): the 2048/4096-point kernel may run
   void* tile_scratch;     // device: fast_rgba_scratch_bytes() of scratch for the fused RGBA output, or nullptr
   uint32_t scale_mode, out_kind, in_kind;
   double gain_db, range_db;
@@ -46,6 +47,10 @@ int launch_stft_general(const StftParams& p, bool exact_f64, void* hip_stream);
 // kernels_fast.hip: float32 kernels with accurate twiddles (returns 1 if this size/mode has no fast kernel).
 int launch_stft_fast(const StftParams& p, void* hip_stream);
 void build_fast_table_1024(std::vector<float>& t);
+// kernels_mw.hip: float32 kernel for 2048- and 4096-point frames with the context's twiddle table
+// (returns 1 if it does not serve this size / layout).
+int launch_stft_mw(const StftParams& p, void* hip_stream);
+bool mw_u8_available(const StftParams& p);
 // kernels_post.hip
 int launch_resample(const uint8_t* in, uint64_t in_frames, uint32_t bins, uint64_t out_width, uint8_t* out,
                     void* hip_stream);
