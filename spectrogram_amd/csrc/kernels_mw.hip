@@ -14,9 +14,12 @@
 // (z = w*(xA + i*xB); XA = (Z[k] + conj Z[N-k])/2, XB = (Z[k] - conj Z[N-k])/(2i)); a third LDS round
 // trip brings Z[k] and Z[N-k] together, and the epilogue fuses |X|^2 -> log2 -> quantiser -> packed uint8.
 //
-// LDS: two planes (re, im) of N floats, index k + (k >> 4) (one pad per 16: the strided accesses of
-// all three exchanges then fall on distinct banks), 34 KiB at N = 4096: four to five workgroups per CU,
-// each on its own barrier, so the CU always has wavefronts in a different phase.
+// LDS: two planes (re, im) of N floats, cell(k) = k + (k >> 5).  A 4-byte LDS access is served in two
+// groups of 32 lanes over 32 banks; with one pad per 32 cells the stride-16 writes of pass A, the
+// (a, c) reads of pass B (lanes 16-31 take c + 2, i.e. 528 = 16 mod 32 cells further), the unit-stride
+// accesses of pass C and the stride-4 reads of the epilogue all fall on 32 distinct banks.  33 KiB at
+// N = 4096: four workgroups per CU, each on its own barrier, so the CU always has wavefronts in a
+// different phase.
 #include <hip/hip_runtime.h>
 
 #include "sono_device.h"
@@ -26,7 +29,7 @@ namespace sono {
 namespace mw {
 
 __host__ __device__ constexpr int rev4(int v) { return ((v & 1) << 3) | ((v & 2) << 1) | ((v & 4) >> 1) | ((v & 8) >> 3); }
-__device__ __forceinline__ int pad(int k) { return k + (k >> 4); }
+__device__ __forceinline__ int pad(int k) { return k + (k >> 5); }
 
 // R-point decimation-in-time network on registers in position order.  tw(half, j): factor (cos, sin) of
 // the butterfly (i, i + half), j = i mod half.  FIRST: j == 0 is the factor (1, 0) exactly.
@@ -78,7 +81,7 @@ template <int LOG2N, bool PLUGIN, typename In>
 __global__ __launch_bounds__((1 << LOG2N) / 16, 4) void stft_mw_kernel(StftParams p, FastScale fs) {
   constexpr int N = 1 << LOG2N, TN = N / 16, CB = LOG2N - 8, NC = 1 << CB, SETS = 16 / NC;
   static_assert(CB >= 3 && CB <= 4, "2048 or 4096 points");
-  constexpr int kPlane = N + N / 16;
+  constexpr int kPlane = N + N / 32;
   __shared__ float s_re[kPlane], s_im[kPlane];
   const int t = threadIdx.x;
   const float2* __restrict__ tw = reinterpret_cast<const float2*>(p.twiddles);
@@ -89,7 +92,7 @@ __global__ __launch_bounds__((1 << LOG2N) / 16, 4) void stft_mw_kernel(StftParam
   const int cA = (int)(__brev((unsigned)(t & (NC - 1))) >> (32 - CB)), bA = rev4(t >> CB);
   const int kA = (cA * 16 + bA) * 16;  // position of register a = 0
   // pass B identity: thread (c, a)
-  const int aB = t & 15, cB = t >> 4;
+  const int aB = t & 15, cB = ((t >> 4) & ~3) | (((t >> 4) & 1) << 1) | (((t >> 4) >> 1) & 1);  // bits 0, 1 of c swapped
   // pass C identity: thread value w = 16b + a (two of them, w and w + 128, at N = 2048)
   float win[16];
 #pragma unroll
@@ -117,9 +120,9 @@ __global__ __launch_bounds__((1 << LOG2N) / 16, 4) void stft_mw_kernel(StftParam
       im[a] *= win[a];
     }
     dit<16, true>(re, im, [&](int half, int j) { return tw[half - 1 + j]; });
-    // LDS cells as one base per thread plus compile-time offsets: pad(k) = k + (k >> 4)
-    const int cellA = kA + (kA >> 4);          // + a
-    const int cellB = cB * 272 + aB;           // + 17 * b
+    // LDS cells as one base per thread plus compile-time offsets
+    const int cellA = kA + (kA >> 5);          // + a            (kA is a multiple of 16: a never carries into k >> 5)
+    const int cellB = cB * 264 + aB;           // + 16 * b + (b >> 1)
 #pragma unroll
     for (int a = 0; a < 16; ++a) {
       s_re[cellA + a] = re[a];
@@ -128,8 +131,8 @@ __global__ __launch_bounds__((1 << LOG2N) / 16, 4) void stft_mw_kernel(StftParam
     __syncthreads();
 #pragma unroll
     for (int b = 0; b < 16; ++b) {
-      re[b] = s_re[cellB + 17 * b];
-      im[b] = s_im[cellB + 17 * b];
+      re[b] = s_re[cellB + 16 * b + (b >> 1)];
+      im[b] = s_im[cellB + 16 * b + (b >> 1)];
     }
     // (the twiddle reads of passes B and C are invariant in this loop; the empty asm keeps them here, out
     // of 60 registers that hoisted copies would hold)
@@ -138,26 +141,26 @@ __global__ __launch_bounds__((1 << LOG2N) / 16, 4) void stft_mw_kernel(StftParam
     dit<16, false>(re, im, [&](int half, int j) { return tw[16 * half - 1 + 16 * j + a_tw]; });
 #pragma unroll
     for (int b = 0; b < 16; ++b) {  // each thread rewrites exactly the cells it read
-      s_re[cellB + 17 * b] = re[b];
-      s_im[cellB + 17 * b] = im[b];
+      s_re[cellB + 16 * b + (b >> 1)] = re[b];
+      s_im[cellB + 16 * b + (b >> 1)] = im[b];
     }
     __syncthreads();
 #pragma unroll
     for (int s = 0; s < SETS; ++s) {
       const int w = t + TN * s;
-      const int cellC = w + (w >> 4);          // + 272 * c
+      const int cellC = w + (w >> 5);          // + 264 * c
 #pragma unroll
       for (int c = 0; c < NC; ++c) {
-        re[s * NC + c] = s_re[cellC + 272 * c];
-        im[s * NC + c] = s_im[cellC + 272 * c];
+        re[s * NC + c] = s_re[cellC + 264 * c];
+        im[s * NC + c] = s_im[cellC + 264 * c];
       }
       int w_tw = w;
       asm volatile("" : "+v"(w_tw));
       dit<NC, false>(re + s * NC, im + s * NC, [&](int half, int j) { return tw[256 * half - 1 + 256 * j + w_tw]; });
 #pragma unroll
       for (int c = 0; c < NC; ++c) {  // X[c*256 + w], again in the thread's own cells
-        s_re[cellC + 272 * c] = re[s * NC + c];
-        s_im[cellC + 272 * c] = im[s * NC + c];
+        s_re[cellC + 264 * c] = re[s * NC + c];
+        s_im[cellC + 264 * c] = im[s * NC + c];
       }
     }
     __syncthreads();
@@ -168,7 +171,7 @@ __global__ __launch_bounds__((1 << LOG2N) / 16, 4) void stft_mw_kernel(StftParam
       const int k = 4 * (t + TN * m);
       if (k >= (int)p.bin_lo && k < (int)p.bin_hi) {
         uint32_t wa = 0, wb = 0;
-        const int cellZ = k + (k >> 4);  // + B (k is a multiple of 4)
+        const int cellZ = k + (k >> 5);  // + B (k is a multiple of 4)
 #define SONO_BIN(B)                                                            \
   {                                                                            \
     const int km = (N - k - B) & (N - 1);                                      \
