@@ -293,7 +293,7 @@ static uint32_t fast_mode_of(const sono_ctx* c) {
 static bool fast_eligible(const sono_ctx* c) { return fast_mode_of(c) != 0; }
 // The 2048/4096-point kernel takes any twiddle table whose stages start with the factor (1, 0).
 static bool mw_eligible(const sono_ctx* c) {
-  if (c->cfg.arith != SONO_ARITH_FAST_F32 || (c->cfg.fft_n != 2048 && c->cfg.fft_n != 4096)) return false;
+  if (c->cfg.arith != SONO_ARITH_FAST_F32 || (c->cfg.fft_n != 512 && c->cfg.fft_n != 2048 && c->cfg.fft_n != 4096)) return false;
   for (uint32_t T = 1; T < c->cfg.fft_n; T <<= 1)
     if (c->h_cos[T - 1] != 1.0 || c->h_sin[T - 1] != 0.0) return false;
   return true;

@@ -1,5 +1,6 @@
-// Float32 STFT kernel for 2048- and 4096-point frames: one workgroup of N/16 threads (2 or 4
-// wavefronts) transforms one pair of real frames per iteration.
+// Float32 STFT kernel for 512-, 2048- and 4096-point frames: a group of N/16 threads transforms one
+// pair of real frames per iteration; a workgroup is one group (2048: 2 wavefronts, 4096: 4) or, at
+// 512 points, eight groups of 32 threads.
 //
 // Dataflow = the reference's radix-2 decimation in time (spectrogramWorker.js:206-253,
 // spectrogram.esm.js:166-200) with its per-stage twiddle TABLE (exact roots for the worker, the
@@ -77,13 +78,15 @@ __device__ __forceinline__ uint32_t put_index(float msq, const FastScale& fs, ui
   }
 }
 
-template <int LOG2N, bool PLUGIN, typename In>
-__global__ __launch_bounds__((1 << LOG2N) / 16, 4) void stft_mw_kernel(StftParams p, FastScale fs) {
+template <int LOG2N, int G, bool PLUGIN, typename In>
+__global__ __launch_bounds__((1 << LOG2N) / 16 * G, 4) void stft_mw_kernel(StftParams p, FastScale fs) {
   constexpr int N = 1 << LOG2N, TN = N / 16, CB = LOG2N - 8, NC = 1 << CB, SETS = 16 / NC;
-  static_assert(CB >= 3 && CB <= 4, "2048 or 4096 points");
+  static_assert(CB >= 1 && CB <= 4, "512 to 4096 points");
   constexpr int kPlane = N + N / 32;
-  __shared__ float s_re[kPlane], s_im[kPlane];
-  const int t = threadIdx.x;
+  __shared__ float s_re_all[G][kPlane], s_im_all[G][kPlane];
+  const int grp = threadIdx.x / TN, t = threadIdx.x % TN;  // group = one transform
+  float* s_re = s_re_all[grp];
+  float* s_im = s_im_all[grp];
   const float2* __restrict__ tw = reinterpret_cast<const float2*>(p.twiddles);
   const In* __restrict__ x = reinterpret_cast<const In*>(p.pcm);
   uint8_t* __restrict__ out = reinterpret_cast<uint8_t*>(p.out);
@@ -92,16 +95,22 @@ __global__ __launch_bounds__((1 << LOG2N) / 16, 4) void stft_mw_kernel(StftParam
   const int cA = (int)(__brev((unsigned)(t & (NC - 1))) >> (32 - CB)), bA = rev4(t >> CB);
   const int kA = (cA * 16 + bA) * 16;  // position of register a = 0
   // pass B identity: thread (c, a)
-  const int aB = t & 15, cB = ((t >> 4) & ~3) | (((t >> 4) & 1) << 1) | (((t >> 4) >> 1) & 1);  // bits 0, 1 of c swapped
+  const int aB = t & 15;
+  const int cB = NC >= 4 ? ((t >> 4) & ~3) | (((t >> 4) & 1) << 1) | (((t >> 4) >> 1) & 1)  // bits 0, 1 of c swapped
+                         : (t >> 4);
   // pass C identity: thread value w = 16b + a (two of them, w and w + 128, at N = 2048)
   float win[16];
 #pragma unroll
   for (int a1 = 0; a1 < 16; ++a1) win[rev4(a1)] = p.window[t + TN * a1];
 
   const uint64_t npairs = (p.nframes + 1) >> 1;
-  for (uint64_t pair = blockIdx.x; pair < npairs; pair += gridDim.x) {
+  for (uint64_t base = (uint64_t)blockIdx.x * G; base < npairs; base += (uint64_t)gridDim.x * G) {
+    // every group of the workgroup goes through every iteration (barriers); one without a pair of its
+    // own repeats the last pair and stores nothing
+    const bool active = base + grp < npairs;
+    const uint64_t pair = active ? base + grp : npairs - 1;
     uint64_t f0 = 2 * pair;
-    bool st_a = true;
+    bool st_a = active;
     if (f0 + 1 >= p.nframes) {  // odd last frame: computed as the second member of the pair before it
       f0 -= 1;
       st_a = false;
@@ -186,7 +195,7 @@ __global__ __launch_bounds__((1 << LOG2N) / 16, 4) void stft_mw_kernel(StftParam
 #undef SONO_BIN
         const uint32_t col = k - p.out_bin0;
         if (st_a) *reinterpret_cast<uint32_t*>(out + row_a + col) = wa;
-        *reinterpret_cast<uint32_t*>(out + row_b + col) = wb;
+        if (active) *reinterpret_cast<uint32_t*>(out + row_b + col) = wb;
       }
     }
     __syncthreads();  // the planes are rewritten by the next pair
@@ -196,7 +205,7 @@ __global__ __launch_bounds__((1 << LOG2N) / 16, 4) void stft_mw_kernel(StftParam
 }  // namespace mw
 
 bool mw_u8_available(const StftParams& p) {
-  if ((p.n != 2048 && p.n != 4096) || !p.mw_ok || !p.twiddles) return false;
+  if ((p.n != 512 && p.n != 2048 && p.n != 4096) || !p.mw_ok || !p.twiddles) return false;
   if ((p.bin_lo & 3) || (p.bin_hi & 3) || (p.out_bins & 3) || (p.out_bin0 & 3)) return false;
   if (p.nframes < 2) return false;
   return true;
@@ -215,18 +224,23 @@ int launch_stft_mw(const StftParams& p, void* stream_v) {
   hipDeviceProp_t prop;
   if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
     cus = prop.multiProcessorCount;
-  const uint64_t cap = (uint64_t)cus * (p.n == 4096 ? 4 : 8);
-  const uint32_t grid = (uint32_t)(npairs < cap ? npairs : cap);
+  const int groups = p.n == 512 ? 8 : 1;  // transforms per workgroup
+  const uint64_t need = (npairs + groups - 1) / groups;
+  const uint64_t cap = (uint64_t)cus * (p.n == 2048 ? 8 : 4);
+  const uint32_t grid = (uint32_t)(need < cap ? need : cap);
   const bool plugin = p.scale_mode == SONO_SCALE_PLUGIN_DB;
-#define SONO_MW(L2, PL, In) hipLaunchKernelGGL((stft_mw_kernel<L2, PL, In>), dim3(grid), dim3((1 << L2) / 16), 0, stream, p, fs)
-#define SONO_MW_IN(L2, PL)                                                 \
-  do {                                                                     \
-    if (p.in_kind == SONO_IN_I16) SONO_MW(L2, PL, int16_t); else SONO_MW(L2, PL, float); \
+#define SONO_MW(L2, GR, PL, In) \
+  hipLaunchKernelGGL((stft_mw_kernel<L2, GR, PL, In>), dim3(grid), dim3((1 << L2) / 16 * GR), 0, stream, p, fs)
+#define SONO_MW_IN(L2, GR, PL)                                                                   \
+  do {                                                                                           \
+    if (p.in_kind == SONO_IN_I16) SONO_MW(L2, GR, PL, int16_t); else SONO_MW(L2, GR, PL, float); \
   } while (0)
   if (p.n == 4096) {
-    if (plugin) SONO_MW_IN(12, true); else SONO_MW_IN(12, false);
+    if (plugin) SONO_MW_IN(12, 1, true); else SONO_MW_IN(12, 1, false);
+  } else if (p.n == 2048) {
+    if (plugin) SONO_MW_IN(11, 1, true); else SONO_MW_IN(11, 1, false);
   } else {
-    if (plugin) SONO_MW_IN(11, true); else SONO_MW_IN(11, false);
+    if (plugin) SONO_MW_IN(9, 8, true); else SONO_MW_IN(9, 8, false);
   }
 #undef SONO_MW_IN
 #undef SONO_MW
