@@ -117,26 +117,32 @@ def main():
         x[s:s + c] = synth_chunk(torch, dev, s, c, 12345 + rank * 1000 + s // blk)
     torch.cuda.synchronize()
 
-    def make_engine(out_kind):
-        eng = E.Engine(fft_n=FFT_N, hop=HOP, window_id=F.WIN_WORKER_HANN, scale_mode=F.SCALE_WORKER_LOG5,
-                       frame_rule=F.FRAMES_WORKER_COMPAT, twiddle_mode=F.TW_ACCURATE, arith=F.ARITH_FAST_F32,
-                       out_kind=out_kind, device=local_rank)
+    OUT_KINDS = {"u8": F.OUT_U8_INDEX, "rgba": F.OUT_RGBA8, "features": F.OUT_FEATURES}
+
+    def make_engine(out_kind, path="worker", fft_n=FFT_N, hop=HOP, **kw):
+        if path == "worker":      # spectrogramWorker.js semantics
+            cfg = dict(window_id=F.WIN_WORKER_HANN, scale_mode=F.SCALE_WORKER_LOG5, frame_rule=F.FRAMES_WORKER_COMPAT,
+                       twiddle_mode=F.TW_ACCURATE)
+        else:                     # spectrogram.esm.js semantics (hann, recurrence twiddles, gain 20 / range 80)
+            cfg = dict(window_id=E.window_id("hann"), scale_mode=F.SCALE_PLUGIN_DB, frame_rule=F.FRAMES_PLUGIN_STRICT,
+                       twiddle_mode=F.TW_PLUGIN_RECURRENCE, gain_db=20.0, range_db=80.0)
+        eng = E.Engine(fft_n=fft_n, hop=hop, arith=F.ARITH_FAST_F32, out_kind=out_kind, device=local_rank, **cfg, **kw)
         eng.set_stream(torch.cuda.current_stream().cuda_stream)
         return eng
 
-    def run(out_name, steps, warmup):
-        kind = F.OUT_U8_INDEX if out_name == "u8" else F.OUT_RGBA8
-        eng = make_engine(kind)
-        nbytes = eng.out_bytes(L)
+    def run(out_name, steps, warmup, samples=None, **eng_kw):
+        eng = make_engine(OUT_KINDS[out_name], **eng_kw)
+        n_in = L if samples is None else min(L, samples)
+        nbytes = eng.out_bytes(n_in)
         out = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-        g = eng.geometry(L)
+        g = eng.geometry(n_in)
         for _ in range(warmup):
-            eng.stft_device(x.data_ptr(), L, out.data_ptr(), nbytes, wait=False)
+            eng.stft_device(x.data_ptr(), n_in, out.data_ptr(), nbytes, wait=False)
         barrier()
         t0 = time.perf_counter()
         eng.timer_start()
         for _ in range(steps):
-            eng.stft_device(x.data_ptr(), L, out.data_ptr(), nbytes, wait=False)
+            eng.stft_device(x.data_ptr(), n_in, out.data_ptr(), nbytes, wait=False)
         ev_ms = eng.timer_stop_ms()          # HIP events on the launch stream
         barrier()
         wall = time.perf_counter() - t0
@@ -186,12 +192,26 @@ def main():
         }
 
     if rank == 0 and world == 1 and not args.no_variants:
-        other = "rgba" if args.out == "u8" else "u8"
-        w2, k2, ob2, _, _ = run(other, max(3, args.steps // 4), 1)
-        result["variants"] = {
-            other: {"value": round(L * max(3, args.steps // 4) / w2 / 1e6, 1), "kernel_ms": round(k2, 4),
-                    "roofline_frac": round((L * 4 + ob2) / (k2 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+        # other entry points of the same path on the same recording (not the headline; same timing method)
+        k = max(3, args.steps // 4)
+        c4 = min(L, 60 * SAMPLE_RATE)
+        specs = {
+            ("rgba" if args.out == "u8" else "u8") + "_worker_1024": dict(out=("rgba" if args.out == "u8" else "u8")),
+            "u8_plugin_getFrequencies_1024": dict(out="u8", path="plugin"),
+            "features_plugin_1024": dict(out="features", path="plugin"),
+            "u8_worker_512_hop128": dict(out="u8", fft_n=512, hop=128),
+            "u8_plugin_2048_hop512": dict(out="u8", path="plugin", fft_n=2048, hop=512),
+            "rgba_plugin_4096_hop256_bins160-1280_60s": dict(out="rgba", path="plugin", fft_n=4096, hop=256, bin_lo=160,
+                                                            bin_hi=1280, samples=c4),
         }
+        result["variants"] = {}
+        for name, sp in specs.items():
+            sp = dict(sp)
+            o = sp.pop("out")
+            n_in = sp.get("samples", L)
+            w2, k2, ob2, _, _ = run(o, k, 1, **sp)
+            result["variants"][name] = {"value": round(n_in * k / w2 / 1e6, 1), "kernel_ms": round(k2, 4),
+                                        "roofline_frac": round((n_in * 4 + ob2) / (k2 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         import oracle
