@@ -214,8 +214,12 @@ def main():
                                         "roofline_frac": round((n_in * 4 + ob2) / (k2 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        import shutil
+        import subprocess
+        import tempfile
         import oracle
         cores = min(16, len(os.sched_getaffinity(0)))
+        # (1) the C restatement of the worker render on `cores` POSIX threads
         probe = x[: 2 * SAMPLE_RATE].cpu().numpy()
         t0 = time.perf_counter()
         oracle.worker_render(probe, FFT_N, 75.0, None, threads=cores)
@@ -225,12 +229,37 @@ def main():
         t0 = time.perf_counter()
         oracle.worker_render(sample, FFT_N, 75.0, None, threads=cores)
         dt = time.perf_counter() - t0
-        result["cpu_baseline"] = {
-            "value": round(len(sample) / dt / 1e6, 2), "unit": "Msamples/s", "cores": cores, "kind": "port",
-            "sample": "first %d s of the same recording (%d samples), RGBA render by the C restatement of "
-                      "spectrogramWorker.js (oracle/), %d POSIX threads" % (secs, len(sample), cores),
-            "seconds": round(dt, 2),
-        }
+        c_port = {"value": round(len(sample) / dt / 1e6, 2), "unit": "Msamples/s", "cores": cores, "kind": "port",
+                  "sample": "first %d s of the same recording (%d samples), RGBA render by the C restatement of "
+                            "spectrogramWorker.js (oracle/sono_oracle.c), %d POSIX threads" % (secs, len(sample), cores),
+                  "seconds": round(dt, 2)}
+        result["cpu_baseline"] = c_port
+        # (2) the same render in the reference's own language and runtime: the JavaScript restatement under
+        #     Node worker_threads, one worker per core, hop-aligned 10 s chunks with a 768-sample halo
+        node = shutil.which("node")
+        js = os.path.join(ROOT, "oracle", "worker_restatement.js")
+        if node and os.path.isfile(js):
+            jsecs, jpasses = 600, 8                                               # about 15 s of CPU work on the GPU box's host cores
+            jsample = x[: min(L, jsecs * SAMPLE_RATE)].cpu().numpy()
+            with tempfile.TemporaryDirectory() as td:
+                f = os.path.join(td, "pcm.f32")
+                jsample.tofile(f)
+                try:
+                    r = subprocess.run([node, js, "bench", f, str(FFT_N), "75", str(cores), "10", str(SAMPLE_RATE), str(jpasses)],
+                                       capture_output=True, text=True, timeout=600)
+                    j = json.loads(r.stdout.strip().splitlines()[-1]) if r.returncode == 0 else None
+                except (subprocess.SubprocessError, ValueError, IndexError):
+                    j = None
+            if j:
+                result["cpu_baseline"] = {
+                    "value": round(j["msamples_per_s"], 2), "unit": "Msamples/s", "cores": cores, "kind": "port",
+                    "sample": "first %d s of the same recording rendered %d times over (%d samples), RGBA render by the JavaScript restatement of "
+                              "spectrogramWorker.js (oracle/worker_restatement.js, byte-identical to the reference on its golden "
+                              "cases) under Node %s worker_threads, %d workers, 10 s chunks" % (
+                                  len(jsample) // SAMPLE_RATE, j["passes"], j["samples"], j["node"], cores),
+                    "seconds": round(j["wall_s"], 2),
+                    "c_port": c_port,
+                }
 
     if world > 1:
         dist.barrier()

@@ -204,3 +204,47 @@ def test_worker_contract_case():
     lut = oracle.worker_lut(G.colormap("rainbow"))
     rgba = oracle.worker_render(G.signal(case["signal"]), case["N"], case["overlap"], lut)
     assert np.array_equal(rgba, G.load(case["rgba"], np.uint8).reshape(case["height"], case["width"], 4))
+
+
+# ------------------------------------------------------------------ the JavaScript restatement (CPU baseline of bench.py)
+@pytest.mark.skipif(__import__("shutil").which("node") is None, reason="node is not installed")
+@pytest.mark.parametrize("case", G.cases("worker_render"), ids=lambda c: c["id"])
+def test_js_worker_restatement_matches_reference_bytes(case, tmp_path):
+    """oracle/worker_restatement.js (timed under worker_threads as bench.py's CPU baseline) renders the
+    golden worker cases to the very bytes the reference produced."""
+    import json
+    import os
+    import subprocess
+    x = G.signal(case["signal"])
+    n, ov = case["N"] or 1024, case["overlap"] or 0
+    inp, outp, lutp = tmp_path / "x.f32", tmp_path / "o.rgba", "-"
+    x.astype(np.float32).tofile(inp)
+    if case["colormap"]:
+        lutp = tmp_path / "lut.u8"
+        G.load(case["lut"], np.uint8).tofile(lutp)
+    js = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "worker_restatement.js")
+    r = subprocess.run(["node", js, "render", str(inp), str(n), str(ov), str(lutp), str(outp)], capture_output=True,
+                       text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    dims = json.loads(r.stdout)
+    assert (dims["width"], dims["height"]) == (case["width"], case["height"])
+    got = np.fromfile(outp, np.uint8).reshape(case["height"], case["width"], 4)
+    assert np.array_equal(got, G.load(case["rgba"], np.uint8).reshape(case["height"], case["width"], 4))
+
+
+@pytest.mark.skipif(__import__("shutil").which("node") is None, reason="node is not installed")
+def test_js_worker_restatement_bench_mode(tmp_path):
+    import json
+    import os
+    import subprocess
+    x = np.tile(G.signal("bat"), 8)
+    inp = tmp_path / "x.f32"
+    x.astype(np.float32).tofile(inp)
+    js = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "worker_restatement.js")
+    r = subprocess.run(["node", js, "bench", str(inp), "1024", "75", "2", "0.05", "384000"], capture_output=True, text=True,
+                       timeout=120)
+    assert r.returncode == 0, r.stderr
+    d = json.loads(r.stdout)
+    assert d["workers"] == 2 and d["chunks"] >= 2 and d["msamples_per_s"] > 0
+    hop = 256
+    assert d["samples"] == (len(x) - 1024) // hop * hop + hop or d["samples"] <= len(x)
