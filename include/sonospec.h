@@ -38,7 +38,8 @@ typedef enum sono_status {
   SONO_ERR_COLORMAP = -4,  /* colour map validation (:213-217)                         */
   SONO_ERR_CAPACITY = -5,  /* output buffer too small                                  */
   SONO_ERR_DEVICE = -6,    /* HIP runtime error, text in sono_last_error               */
-  SONO_ERR_NO_DEVICE = -7  /* no usable GPU                                            */
+  SONO_ERR_NO_DEVICE = -7, /* no usable GPU                                            */
+  SONO_ERR_FORMAT = -8     /* malformed RIFF/WAVE data (where the reference's DataView read throws) */
 } sono_status;
 
 /* Window functions in the order of the plugin's switch, spectrogram.esm.js:105-151. */
@@ -246,6 +247,64 @@ void* sono_device_malloc(sono_ctx* ctx, uint64_t bytes);
 int sono_device_free(sono_ctx* ctx, void* p);
 int sono_copy_to_device(sono_ctx* ctx, void* dst_dev, const void* src_host, uint64_t bytes);
 int sono_copy_to_host(sono_ctx* ctx, void* dst_host, const void* src_dev, uint64_t bytes);
+
+/* ---- file intake: RIFF/WAVE, GUANO, crop by time (host side) ------------------------------- */
+
+/* What the reference's three chunk walks find in a .wav file (chunks from offset 12, odd sizes padded). */
+typedef struct sono_wav_info {
+  uint32_t sample_rate;        /* getWavSampleRate, fileLoader.js:7-27: rate of the FIRST fmt chunk, 256000 if none */
+  uint32_t has_fmt;            /* a fmt chunk was seen before the data chunk (getWavDuration / cropWavBlob rule)    */
+  uint32_t has_data;
+  uint32_t fmt_sample_rate;    /* rate of the last fmt chunk before the data chunk                                  */
+  uint16_t format_tag;         /* 1 PCM, 3 IEEE float; WAVE_FORMAT_EXTENSIBLE is resolved to its sub-format         */
+  uint16_t channels;
+  uint16_t bits_per_sample;
+  uint16_t reserved0;
+  uint32_t block_align;        /* channels * bits_per_sample / 8                                                    */
+  uint32_t fmt_bytes;
+  uint64_t fmt_offset;         /* payload offset of that fmt chunk                                                  */
+  uint64_t data_offset;        /* payload offset of the data chunk                                                  */
+  uint64_t data_bytes;         /* its declared size                                                                 */
+  uint64_t data_bytes_present; /* ... clipped to the end of the file                                                */
+  uint64_t frames;             /* sample frames present                                                             */
+  double duration_s;           /* getWavDuration, fileLoader.js:29-63 (0 when fmt or data is missing)                */
+} sono_wav_info;
+int sono_wav_parse(const void* file, uint64_t bytes, sono_wav_info* out);
+
+/* extractGuanoMetadata, guanoReader.js:3-34: payload of the first chunk (any id) whose bytes contain
+ * "GUANO|Version:"; *length == 0 when there is none (the reference then returns "(No GUANO metadata
+ * found in file)").  SONO_ERR_FORMAT where the reference's reads throw (truncated chunk). */
+int sono_wav_guano(const void* file, uint64_t bytes, uint64_t* offset, uint64_t* length);
+
+/* parseGuanoMetadata, guanoReader.js:36-80.  present == 0 stands for the reference's empty object (empty
+ * text or the "(No GUANO" placeholder).  Strings longer than the fields are truncated. */
+typedef struct sono_guano_fields_t {
+  int32_t present;
+  char date[64];      /* Timestamp's date part with '-' -> '/'                                   */
+  char time[16];      /* first five characters of the time part without its first ':' ("2015")   */
+  char latitude[64];  /* first token of "Loc Position"                                           */
+  char longitude[64]; /* second token through parseFloat / Number.toString, -113..-115 made positive */
+} sono_guano_fields_t;
+int sono_guano_fields(const char* text, uint64_t bytes, sono_guano_fields_t* out);
+
+/* cropWavBlob, cropAudio.js:1-59: the file's bytes up to the data payload followed by the samples of
+ * [floor(start*rate), floor(end*rate)), RIFF and data sizes patched; chunks after the data are dropped.
+ * Returns the number of bytes written (with out == NULL: needed), 0 where the reference returns null,
+ * or a negative sono_status. */
+int64_t sono_wav_crop(const void* file, uint64_t bytes, double start_s, double end_s, void* out, uint64_t capacity);
+
+/* The load filters of fileLoader.js:179-181: 0 accept, 1 skipped as small (< 200 KiB), 2 skipped as long
+ * (> 20 s unless time-expansion mode). */
+int sono_wav_accept(uint64_t file_bytes, double duration_s, int time_expansion);
+
+/* Interleaved PCM -> one channel of float32 on the device, without a host-side float copy.
+ * format_tag 1: 8-bit unsigned ((v-128)/128), 16 (v/32768), 24 (v/8388608), 32 (v/2147483648);
+ * format_tag 3: float32 as is.  The browser's decodeAudioData is not reproducible offline, so these
+ * scalings are this library's convention (16-bit matches SONO_IN_I16).  `src` is host or device memory
+ * (`mem`), `dst_dev` device memory for `frames` floats.  Asynchronous on the context's stream for
+ * device sources. */
+int sono_pcm_to_f32(sono_ctx* ctx, const void* src, int mem, uint32_t format_tag, uint32_t bits_per_sample, uint32_t channels,
+                    uint32_t channel, uint64_t frames, float* dst_dev);
 
 /* ---- timing (HIP events on the context's stream) ------------------------------------------ */
 

@@ -527,6 +527,134 @@ static napi_value js_geometry_for(napi_env env, napi_callback_info info) {
   return geometry_object(env, &g);
 }
 
+/* ---- file intake (host side) ----------------------------------------------------------------- */
+
+static void set_num(napi_env env, napi_value obj, const char* name, double v) { napi_set_named_property(env, obj, name, make_num(env, v)); }
+static void set_str(napi_env env, napi_value obj, const char* name, const char* v) {
+  napi_value sv;
+  napi_create_string_utf8(env, v, NAPI_AUTO_LENGTH, &sv);
+  napi_set_named_property(env, obj, name, sv);
+}
+
+/* wavParse(Uint8Array) -> {sampleRate, hasFmt, hasData, fmtSampleRate, formatTag, channels, bitsPerSample, blockAlign,
+ *                          dataOffset, dataBytes, dataBytesPresent, frames, duration} */
+static napi_value js_wav_parse(napi_env env, napi_callback_info info) {
+  ARGS(env, info, 1);
+  napi_typedarray_type t;
+  void* data;
+  int64_t n = ta_data(env, argv[0], &t, &data);
+  if (n < 0 || t != napi_uint8_array) return throw_msg(env, "wavParse(Uint8Array)");
+  sono_wav_info w;
+  if (sono_wav_parse(data, (uint64_t)n, &w) != SONO_OK) {
+    napi_throw_range_error(env, NULL, "Offset is outside the bounds of the DataView");
+    return NULL;
+  }
+  napi_value o;
+  napi_create_object(env, &o);
+  set_num(env, o, "sampleRate", w.sample_rate);
+  set_num(env, o, "hasFmt", w.has_fmt);
+  set_num(env, o, "hasData", w.has_data);
+  set_num(env, o, "fmtSampleRate", w.fmt_sample_rate);
+  set_num(env, o, "formatTag", w.format_tag);
+  set_num(env, o, "channels", w.channels);
+  set_num(env, o, "bitsPerSample", w.bits_per_sample);
+  set_num(env, o, "blockAlign", w.block_align);
+  set_num(env, o, "dataOffset", (double)w.data_offset);
+  set_num(env, o, "dataBytes", (double)w.data_bytes);
+  set_num(env, o, "dataBytesPresent", (double)w.data_bytes_present);
+  set_num(env, o, "frames", (double)w.frames);
+  set_num(env, o, "duration", w.duration_s);
+  return o;
+}
+
+/* wavGuano(Uint8Array) -> [offset, length] (length 0: none) */
+static napi_value js_wav_guano(napi_env env, napi_callback_info info) {
+  ARGS(env, info, 1);
+  napi_typedarray_type t;
+  void* data;
+  int64_t n = ta_data(env, argv[0], &t, &data);
+  if (n < 0 || t != napi_uint8_array) return throw_msg(env, "wavGuano(Uint8Array)");
+  uint64_t off = 0, len = 0;
+  if (sono_wav_guano(data, (uint64_t)n, &off, &len) != SONO_OK) {
+    napi_throw_range_error(env, NULL, "Offset is outside the bounds of the DataView");
+    return NULL;
+  }
+  napi_value arr;
+  napi_create_array_with_length(env, 2, &arr);
+  napi_set_element(env, arr, 0, make_num(env, (double)off));
+  napi_set_element(env, arr, 1, make_num(env, (double)len));
+  return arr;
+}
+
+/* guanoFields(Uint8Array utf8) -> {} | {date, time, latitude, longitude} */
+static napi_value js_guano_fields(napi_env env, napi_callback_info info) {
+  ARGS(env, info, 1);
+  napi_typedarray_type t;
+  void* data;
+  int64_t n = ta_data(env, argv[0], &t, &data);
+  if (n < 0 || (n > 0 && t != napi_uint8_array)) return throw_msg(env, "guanoFields(Uint8Array)");
+  sono_guano_fields_t g;
+  if (sono_guano_fields((const char*)data, (uint64_t)n, &g) != SONO_OK) return throw_msg(env, "guanoFields failed");
+  napi_value o;
+  napi_create_object(env, &o);
+  if (g.present) {
+    set_str(env, o, "date", g.date);
+    set_str(env, o, "time", g.time);
+    set_str(env, o, "latitude", g.latitude);
+    set_str(env, o, "longitude", g.longitude);
+  }
+  return o;
+}
+
+/* wavCrop(Uint8Array, startSeconds, endSeconds) -> Uint8Array | null */
+static napi_value js_wav_crop(napi_env env, napi_callback_info info) {
+  ARGS(env, info, 3);
+  napi_typedarray_type t;
+  void* data;
+  double t0, t1;
+  int64_t n = ta_data(env, argv[0], &t, &data);
+  if (n < 0 || t != napi_uint8_array || !get_f64(env, argv[1], &t0) || !get_f64(env, argv[2], &t1))
+    return throw_msg(env, "wavCrop(Uint8Array, start, end)");
+  int64_t need = sono_wav_crop(data, (uint64_t)n, t0, t1, NULL, 0);
+  if (need < 0) return throw_msg(env, "wavCrop: unsupported file or times");
+  napi_value nul;
+  napi_get_null(env, &nul);
+  if (need == 0) return nul;
+  void* out;
+  napi_value ta = new_typed(env, napi_uint8_array, (size_t)need, 1, &out);
+  if (!ta) return NULL;
+  if (sono_wav_crop(data, (uint64_t)n, t0, t1, out, (uint64_t)need) != need) return throw_msg(env, "wavCrop failed");
+  return ta;
+}
+
+/* wavAccept(fileBytes, duration, timeExpansion) -> 0 | 1 | 2 */
+static napi_value js_wav_accept(napi_env env, napi_callback_info info) {
+  ARGS(env, info, 2);
+  uint64_t fb;
+  double d;
+  bool te = false;
+  if (!get_u64(env, argv[0], &fb) || !get_f64(env, argv[1], &d)) return throw_msg(env, "wavAccept(fileBytes, duration[, timeExpansion])");
+  if (argc > 2) napi_get_value_bool(env, argv[2], &te);
+  return make_num(env, sono_wav_accept(fb, d, te ? 1 : 0));
+}
+
+/* pcmToDevice(handle, Uint8Array raw, formatTag, bits, channels, channel, dstPtr) */
+static napi_value js_pcm_to_device(napi_env env, napi_callback_info info) {
+  ARGS(env, info, 7);
+  handle_t* h = get_handle(env, argv[0]);
+  napi_typedarray_type t;
+  void *data, *dst;
+  uint32_t tag, bits, ch, c;
+  int64_t n = ta_data(env, argv[1], &t, &data);
+  if (!h || n < 0 || t != napi_uint8_array || !get_u32(env, argv[2], &tag) || !get_u32(env, argv[3], &bits) || !get_u32(env, argv[4], &ch) ||
+      !get_u32(env, argv[5], &c) || !get_ptr(env, argv[6], &dst) || !ch || bits < 8)
+    return throw_msg(env, "pcmToDevice(handle, raw, formatTag, bits, channels, channel, dstPtr)");
+  const uint64_t frames = (uint64_t)n / ((uint64_t)ch * (bits / 8));
+  int rc = sono_pcm_to_f32(h->ctx, data, SONO_MEM_HOST, tag, bits, ch, c, frames, (float*)dst);
+  if (rc != SONO_OK) return throw_ctx(env, h, rc);
+  return make_num(env, (double)frames);
+}
+
 #define EXPORT(name, fn)                                                     \
   do {                                                                       \
     napi_value f_;                                                           \
@@ -562,6 +690,12 @@ static napi_value init(napi_env env, napi_value exports) {
   EXPORT("workerLut", js_worker_lut);
   EXPORT("windowTable", js_window_table);
   EXPORT("geometryFor", js_geometry_for);
+  EXPORT("wavParse", js_wav_parse);
+  EXPORT("wavGuano", js_wav_guano);
+  EXPORT("guanoFields", js_guano_fields);
+  EXPORT("wavCrop", js_wav_crop);
+  EXPORT("wavAccept", js_wav_accept);
+  EXPORT("pcmToDevice", js_pcm_to_device);
   napi_set_named_property(env, exports, "abiVersion", make_num(env, sono_abi_version()));
   return exports;
 }

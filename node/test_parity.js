@@ -74,6 +74,30 @@ for (const c of cases('worker_tables')) {
   ok(equal(S.workerHann(c.N), load(c.hann, Float32Array)), 'worker hann ' + c.N);
 }
 
+// file intake against the reference's own answers (tests/golden/wav)
+{
+  const wav = require('./wav.js');
+  const wm = JSON.parse(fs.readFileSync(path.join(G, 'wav', 'manifest.json'), 'utf8'));
+  const same = (a, b) => JSON.stringify(a) === JSON.stringify(b);
+  let bad = 0;
+  for (const c of wm.files) {
+    const data = fs.readFileSync(path.join(G, c.file));
+    if (wav.getWavSampleRate(data) !== c.sample_rate) bad++;
+    if (wav.getWavDuration(data) !== c.duration) bad++;
+    if (wav.extractGuanoMetadata(data) !== c.guano_text) bad++;
+    if (!same(wav.parseGuanoMetadata(c.guano_text), c.guano_fields)) bad++;
+    for (const k of c.crops) {
+      const got = wav.cropWavBlob(data, k.start, k.end);
+      if (k.result === null) { if (got !== null) bad++; }
+      else if (!got || !equal(got, new Uint8Array(fs.readFileSync(path.join(G, k.result))))) bad++;
+    }
+  }
+  for (const t of wm.guano_texts) if (!same(wav.parseGuanoMetadata(t.text), t.fields)) bad++;
+  ok(bad === 0 && wm.files.length >= 9, 'wav / guano / crop against the reference, mismatches: ' + bad);
+  ok(wav.getWavSampleRate(null) === 256000 && wav.getWavDuration(null) === 0 && wav.extractGuanoMetadata(null) === '(no file selected)' &&
+     wav.acceptFile(1000, 1) === 'small' && wav.acceptFile(1e7, 21) === 'long' && wav.acceptFile(1e7, 21, true) === 'ok', 'wav defaults and filters');
+}
+
 // matcher semantics over the reference's own rule table and verdicts
 {
   const { autoIdHK, segmentCalls, callToAutoIdData } = require('./autoid.js');

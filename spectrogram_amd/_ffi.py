@@ -14,6 +14,7 @@ LIB_PATH = os.path.join(_HERE, "libsonospec.so")
 # enums of include/sonospec.h
 OK = 0
 ERR_ARG, ERR_WINDOW, ERR_FFT_SIZE, ERR_COLORMAP, ERR_CAPACITY, ERR_DEVICE, ERR_NO_DEVICE = -1, -2, -3, -4, -5, -6, -7
+ERR_FORMAT = -8
 WINDOW_IDS = {
     "bartlett": 0, "bartlettHann": 1, "blackman": 2, "cosine": 3, "gauss": 4,
     "hamming": 5, "hann": 6, "lanczoz": 7, "rectangular": 8, "triangular": 9,
@@ -43,6 +44,20 @@ CALL_DTYPE = np.dtype([("start_frame", np.uint64), ("end_frame", np.uint64), ("p
                        ("peak_bin", np.int32), ("peak_idx", np.uint32)])
 
 
+class SonoWavInfo(C.Structure):
+    _fields_ = [
+        ("sample_rate", C.c_uint32), ("has_fmt", C.c_uint32), ("has_data", C.c_uint32), ("fmt_sample_rate", C.c_uint32),
+        ("format_tag", C.c_uint16), ("channels", C.c_uint16), ("bits_per_sample", C.c_uint16), ("reserved0", C.c_uint16),
+        ("block_align", C.c_uint32), ("fmt_bytes", C.c_uint32), ("fmt_offset", C.c_uint64), ("data_offset", C.c_uint64),
+        ("data_bytes", C.c_uint64), ("data_bytes_present", C.c_uint64), ("frames", C.c_uint64), ("duration_s", C.c_double),
+    ]
+
+
+class SonoGuanoFields(C.Structure):
+    _fields_ = [("present", C.c_int32), ("date", C.c_char * 64), ("time", C.c_char * 16), ("latitude", C.c_char * 64),
+                ("longitude", C.c_char * 64)]
+
+
 class SonoGeometry(C.Structure):
     _fields_ = [("frames", C.c_uint64), ("width", C.c_uint64), ("bins", C.c_uint32), ("hop", C.c_uint32)]
 
@@ -50,6 +65,13 @@ class SonoGeometry(C.Structure):
 # every symbol include/sonospec.h declares: name -> (restype, argtypes)
 _VP = C.c_void_p
 SYMBOLS = {
+    "sono_wav_parse": (C.c_int, [C.c_void_p, C.c_uint64, C.POINTER(SonoWavInfo)]),
+    "sono_wav_guano": (C.c_int, [C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "sono_guano_fields": (C.c_int, [C.c_char_p, C.c_uint64, C.POINTER(SonoGuanoFields)]),
+    "sono_wav_crop": (C.c_int64, [C.c_void_p, C.c_uint64, C.c_double, C.c_double, C.c_void_p, C.c_uint64]),
+    "sono_wav_accept": (C.c_int, [C.c_uint64, C.c_double, C.c_int]),
+    "sono_pcm_to_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64,
+                                  C.c_void_p]),
     "sono_abi_version": (C.c_int, []),
     "sono_device_count": (C.c_int, []),
     "sono_worker_hop": (C.c_uint32, [C.c_uint32, C.c_double]),

@@ -433,6 +433,27 @@ int sono_stft_async(sono_ctx* c, const void* pcm, uint64_t L, void* out, uint64_
   return SONO_OK;
 }
 
+int sono_pcm_to_f32(sono_ctx* c, const void* src, int mem, uint32_t format_tag, uint32_t bits, uint32_t channels, uint32_t channel,
+                    uint64_t frames, float* dst_dev) {
+  if (!c) return SONO_ERR_ARG;
+  if (!src || !dst_dev || !channels || channel >= channels) return fail(c, SONO_ERR_ARG, "bad PCM layout");
+  const bool ok = (format_tag == 3 && bits == 32) || (format_tag == 1 && (bits == 8 || bits == 16 || bits == 24 || bits == 32));
+  if (!ok) return fail(c, SONO_ERR_ARG, "unsupported PCM format (tag %u, %u bits)", format_tag, bits);
+  HIP_TRY(c, hipSetDevice(c->device));
+  const void* dsrc = src;
+  if (mem == SONO_MEM_HOST) {  // raw bytes cross PCIe; the float array exists on the device only
+    const uint64_t nbytes = frames * channels * (bits / 8);
+    int rc = ensure(c, &c->d_in, &c->d_in_bytes, nbytes);
+    if (rc != SONO_OK) return rc;
+    HIP_TRY(c, hipMemcpyAsync(c->d_in, src, nbytes, hipMemcpyHostToDevice, c->stream));
+    dsrc = c->d_in;
+  }
+  int r = launch_pcm_to_f32(dsrc, format_tag, bits, channels, channel, frames, dst_dev, c->stream);
+  if (r != SONO_OK) return fail(c, r, "PCM conversion launch failed");
+  if (mem == SONO_MEM_HOST) HIP_TRY(c, hipStreamSynchronize(c->stream));  // the staging buffer is reused by the next call
+  return SONO_OK;
+}
+
 int sono_wait(sono_ctx* c) {
   if (!c) return SONO_ERR_ARG;
   HIP_TRY(c, hipStreamSynchronize(c->stream));

@@ -158,4 +158,45 @@ int launch_frame_peaks(const uint8_t* idx, uint64_t frames, uint32_t bins, int32
   return hipGetLastError() == hipSuccess ? SONO_OK : SONO_ERR_DEVICE;
 }
 
+// One channel of interleaved PCM -> float32.  KIND: 0 u8, 1 i16, 2 i24, 3 i32, 4 f32.
+template <int KIND>
+__global__ __launch_bounds__(256) void pcm_to_f32_kernel(const uint8_t* __restrict__ src, uint32_t channels, uint32_t channel,
+                                                         uint64_t frames, float* __restrict__ dst) {
+  const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= frames) return;
+  constexpr int kBytes = KIND == 0 ? 1 : KIND == 1 ? 2 : KIND == 2 ? 3 : 4;
+  const uint8_t* p = src + (i * channels + channel) * kBytes;
+  float v;
+  if constexpr (KIND == 0) {
+    v = ((float)p[0] - 128.0f) * (1.0f / 128.0f);
+  } else if constexpr (KIND == 1) {
+    v = (float)(int16_t)(p[0] | (p[1] << 8)) * (1.0f / 32768.0f);
+  } else if constexpr (KIND == 2) {
+    const int32_t w = (int32_t)((uint32_t)p[0] << 8 | (uint32_t)p[1] << 16 | (uint32_t)p[2] << 24) >> 8;
+    v = (float)w * (1.0f / 8388608.0f);
+  } else if constexpr (KIND == 3) {
+    const int32_t w = (int32_t)((uint32_t)p[0] | (uint32_t)p[1] << 8 | (uint32_t)p[2] << 16 | (uint32_t)p[3] << 24);
+    v = (float)((double)w * (1.0 / 2147483648.0));
+  } else {
+    const uint32_t w = (uint32_t)p[0] | (uint32_t)p[1] << 8 | (uint32_t)p[2] << 16 | (uint32_t)p[3] << 24;
+    v = __uint_as_float(w);
+  }
+  dst[i] = v;
+}
+
+int launch_pcm_to_f32(const void* src, uint32_t format_tag, uint32_t bits, uint32_t channels, uint32_t channel, uint64_t frames,
+                      float* dst, void* stream_v) {
+  if (!frames) return SONO_OK;
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_v);
+  const uint8_t* s = reinterpret_cast<const uint8_t*>(src);
+  const dim3 grid((unsigned)((frames + 255) / 256)), block(256);
+  if (format_tag == 3 && bits == 32) hipLaunchKernelGGL(pcm_to_f32_kernel<4>, grid, block, 0, stream, s, channels, channel, frames, dst);
+  else if (format_tag == 1 && bits == 8) hipLaunchKernelGGL(pcm_to_f32_kernel<0>, grid, block, 0, stream, s, channels, channel, frames, dst);
+  else if (format_tag == 1 && bits == 16) hipLaunchKernelGGL(pcm_to_f32_kernel<1>, grid, block, 0, stream, s, channels, channel, frames, dst);
+  else if (format_tag == 1 && bits == 24) hipLaunchKernelGGL(pcm_to_f32_kernel<2>, grid, block, 0, stream, s, channels, channel, frames, dst);
+  else if (format_tag == 1 && bits == 32) hipLaunchKernelGGL(pcm_to_f32_kernel<3>, grid, block, 0, stream, s, channels, channel, frames, dst);
+  else return SONO_ERR_ARG;
+  return hipGetLastError() == hipSuccess ? SONO_OK : SONO_ERR_DEVICE;
+}
+
 }  // namespace sono

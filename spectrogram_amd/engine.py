@@ -124,6 +124,54 @@ class Engine:
     def wait(self):
         self._check(self._lib.sono_wait(self._ctx))
 
+    # -- device memory owned by the caller
+    def device_malloc(self, nbytes):
+        p = self._lib.sono_device_malloc(self._ctx, int(nbytes))
+        if not p:
+            raise F.SonoError(F.ERR_DEVICE, self._lib.sono_last_error(self._ctx).decode())
+        return p
+
+    def device_free(self, ptr):
+        self._lib.sono_device_free(self._ctx, C.c_void_p(ptr))
+
+    def copy_to_host(self, arr, ptr):
+        self._check(self._lib.sono_copy_to_host(self._ctx, F.ptr(arr), C.c_void_p(ptr), arr.nbytes))
+        return arr
+
+    def pcm_to_device(self, raw, format_tag, bits, channels=1, channel=0):
+        """Interleaved PCM bytes (host) -> float32 samples of one channel in device memory.  Returns
+        (device pointer, frames); free it with device_free."""
+        raw = np.ascontiguousarray(np.frombuffer(raw, np.uint8) if not isinstance(raw, np.ndarray) else raw.view(np.uint8))
+        frames = raw.size // (int(channels) * (int(bits) // 8))
+        dst = self.device_malloc(max(4, frames * 4))
+        rc = self._lib.sono_pcm_to_f32(self._ctx, F.ptr(raw), F.MEM_HOST, int(format_tag), int(bits), int(channels), int(channel),
+                                       frames, C.c_void_p(dst))
+        if rc != F.OK:
+            self.device_free(dst)
+            self._check(rc)
+        return dst, frames
+
+    def stft_wav(self, data, channel=0):
+        """One .wav file (bytes) -> this context's output: chunk walk on the host, raw PCM over PCIe,
+        conversion and transform on the device.  Contexts for this call take float32 input."""
+        from . import intake
+        if self.cfg.in_kind != F.IN_F32:
+            raise ValueError("stft_wav converts to float32 on the device: create the context with in_kind = IN_F32")
+        raw, w = intake.pcm_samples(data)
+        dpcm, frames = self.pcm_to_device(raw, w.format_tag, w.bits_per_sample, w.channels, channel)
+        try:
+            out = self._out_array(frames)
+            dout = self.device_malloc(max(4, out.nbytes))
+            try:
+                self.stft_device(dpcm, frames, dout, out.nbytes)
+                if out.nbytes:
+                    self.copy_to_host(out, dout)
+            finally:
+                self.device_free(dout)
+        finally:
+            self.device_free(dpcm)
+        return out, w
+
     def resample(self, frames, out_width):
         frames = np.ascontiguousarray(frames, np.uint8)
         Fr, B = frames.shape
