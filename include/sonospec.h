@@ -227,6 +227,15 @@ int sono_stft(sono_ctx* ctx, const void* pcm, uint64_t n_samples, void* out, uin
 int sono_stft_async(sono_ctx* ctx, const void* pcm_dev, uint64_t n_samples, void* out_dev, uint64_t out_capacity_bytes);
 int sono_wait(sono_ctx* ctx);
 
+/* Host pointers, enqueued without waiting: copy in, transform, copy out on the context's stream, through
+ * the context's staging buffers (so: one transform in flight per context; a batch host cycles over a
+ * few contexts to overlap the copies of one file with the transform of another).  The copies only run
+ * asynchronously from page-locked memory (sono_host_malloc).  No counterpart in the reference (its
+ * worker gets a transferred ArrayBuffer, main.js:1417). */
+int sono_stft_host_async(sono_ctx* ctx, const void* pcm_host, uint64_t n_samples, void* out_host, uint64_t out_capacity_bytes);
+void* sono_host_malloc(uint64_t bytes);
+int sono_host_free(void* p);
+
 /* resample (spectrogram.esm.js:595-640): [in_frames][bins] uint8 -> [out_width][bins] uint8. */
 int sono_resample(sono_ctx* ctx, const uint8_t* in, uint64_t in_frames, uint32_t bins, uint64_t out_width,
                   uint8_t* out, int mem);

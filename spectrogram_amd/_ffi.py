@@ -65,6 +65,9 @@ class SonoGeometry(C.Structure):
 # every symbol include/sonospec.h declares: name -> (restype, argtypes)
 _VP = C.c_void_p
 SYMBOLS = {
+    "sono_stft_host_async": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64]),
+    "sono_host_malloc": (C.c_void_p, [C.c_uint64]),
+    "sono_host_free": (C.c_int, [C.c_void_p]),
     "sono_wav_parse": (C.c_int, [C.c_void_p, C.c_uint64, C.POINTER(SonoWavInfo)]),
     "sono_wav_guano": (C.c_int, [C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "sono_guano_fields": (C.c_int, [C.c_char_p, C.c_uint64, C.POINTER(SonoGuanoFields)]),

@@ -460,13 +460,8 @@ int sono_wait(sono_ctx* c) {
   return SONO_OK;
 }
 
-int sono_stft(sono_ctx* c, const void* pcm, uint64_t L, void* out, uint64_t cap, int mem) {
+int sono_stft_host_async(sono_ctx* c, const void* pcm, uint64_t L, void* out, uint64_t cap) {
   if (!c) return SONO_ERR_ARG;
-  if (mem == SONO_MEM_DEVICE) {
-    int rc = sono_stft_async(c, pcm, L, out, cap);
-    return rc != SONO_OK ? rc : sono_wait(c);
-  }
-  if (mem != SONO_MEM_HOST) return fail(c, SONO_ERR_ARG, "mem must be SONO_MEM_HOST or SONO_MEM_DEVICE");
   if (!out || (!pcm && L)) return fail(c, SONO_ERR_ARG, "NULL buffer");
   const uint64_t need = sono_out_bytes(c, L);
   if (cap < need) return fail(c, SONO_ERR_CAPACITY, "output needs %llu bytes, capacity is %llu", (unsigned long long)need,
@@ -480,8 +475,27 @@ int sono_stft(sono_ctx* c, const void* pcm, uint64_t L, void* out, uint64_t cap,
   rc = sono_stft_async(c, c->d_in, L, c->d_out, c->d_out_bytes);
   if (rc != SONO_OK) return rc;
   if (need) HIP_TRY(c, hipMemcpyAsync(out, c->d_out, need, hipMemcpyDeviceToHost, c->stream));
-  return sono_wait(c);
+  return SONO_OK;
 }
+
+int sono_stft(sono_ctx* c, const void* pcm, uint64_t L, void* out, uint64_t cap, int mem) {
+  if (!c) return SONO_ERR_ARG;
+  if (mem == SONO_MEM_DEVICE) {
+    int rc = sono_stft_async(c, pcm, L, out, cap);
+    return rc != SONO_OK ? rc : sono_wait(c);
+  }
+  if (mem != SONO_MEM_HOST) return fail(c, SONO_ERR_ARG, "mem must be SONO_MEM_HOST or SONO_MEM_DEVICE");
+  int rc = sono_stft_host_async(c, pcm, L, out, cap);
+  return rc != SONO_OK ? rc : sono_wait(c);
+}
+
+void* sono_host_malloc(uint64_t bytes) {
+  void* p = nullptr;
+  if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) return nullptr;
+  return p;
+}
+
+int sono_host_free(void* p) { return (!p || hipHostFree(p) == hipSuccess) ? SONO_OK : SONO_ERR_DEVICE; }
 
 int sono_resample(sono_ctx* c, const uint8_t* in, uint64_t F, uint32_t bins, uint64_t W, uint8_t* out, int mem) {
   if (!c) return SONO_ERR_ARG;

@@ -91,3 +91,87 @@ def gather_results(local, dst=0):
     out = [None] * dist.get_world_size() if dist.get_rank() == dst else None
     dist.gather_object(local, out, dst=dst)
     return out
+
+
+class FilePipeline:
+    """Many short recordings through one GPU with the copies overlapped: `slots` contexts, each with its
+    own stream, device staging and a pair of page-locked host buffers; file i goes to slot i % slots, so
+    while one file is being transformed the next one is on its way in and the previous result on its
+    way out (PCIe is full duplex).  This is the per-file batch path (the reference handles one file at
+    a time, modules/fileLoader.js:110-157; its worker receives a transferred buffer, main.js:1417).
+
+    All files of a pipeline share one configuration and must not exceed `max_samples`.
+    """
+
+    def __init__(self, max_samples, slots=3, copy=True, **engine_kw):
+        self._copy = copy   # False: yield views of the page-locked output buffers (valid until the slot is reused)
+        import ctypes as C
+        import numpy as np
+        self._np, self._C = np, C
+        self._lib = F.lib()
+        self.engines = [E.Engine(**engine_kw) for _ in range(slots)]
+        e0 = self.engines[0]
+        self._in_dt = np.int16 if e0.cfg.in_kind == F.IN_I16 else np.float32
+        self._in_bytes = int(max_samples) * np.dtype(self._in_dt).itemsize
+        self._out_bytes = int(e0.out_bytes(int(max_samples)))
+        self.max_samples = int(max_samples)
+        self._pin_in, self._pin_out, self._busy = [], [], [None] * slots
+        for _ in range(slots):
+            pi, po = self._lib.sono_host_malloc(max(4, self._in_bytes)), self._lib.sono_host_malloc(max(4, self._out_bytes))
+            if not pi or not po:
+                raise F.SonoError(F.ERR_DEVICE, "page-locked host allocation failed")
+            self._pin_in.append(pi)
+            self._pin_out.append(po)
+
+    def _view(self, ptr, nbytes, dtype):
+        buf = (self._C.c_uint8 * nbytes).from_address(ptr)
+        return self._np.frombuffer(buf, dtype=dtype)
+
+    def _collect(self, s):
+        tag, n, shape_of = self._busy[s]
+        self.engines[s].wait()
+        out = self.engines[s]._out_array(n) if self._copy else None
+        if out is not None:
+            out.reshape(-1).view(self._np.uint8)[:] = self._view(self._pin_out[s], out.nbytes, self._np.uint8)
+        else:
+            out = self._view(self._pin_out[s], int(self.engines[s].out_bytes(n)), self._np.uint8)
+        self._busy[s] = None
+        return tag, out
+
+    def run(self, files):
+        """files: iterable of (tag, samples array).  Yields (tag, output) in submission order."""
+        np = self._np
+        i = 0
+        for tag, x in files:
+            s = i % len(self.engines)
+            if self._busy[s] is not None:
+                yield self._collect(s)
+            x = np.ascontiguousarray(x, self._in_dt).reshape(-1)
+            if x.shape[0] > self.max_samples:
+                raise ValueError("file longer than the pipeline's max_samples")
+            self._view(self._pin_in[s], x.nbytes, self._in_dt)[:] = x
+            eng = self.engines[s]
+            need = int(eng.out_bytes(x.shape[0]))
+            eng._check(self._lib.sono_stft_host_async(eng._ctx, self._C.c_void_p(self._pin_in[s]), x.shape[0],
+                                                      self._C.c_void_p(self._pin_out[s]), need))
+            self._busy[s] = (tag, x.shape[0], None)
+            i += 1
+        # drain in submission order
+        n = len(self.engines)
+        for k in range(n):
+            s = (i + k) % n
+            if self._busy[s] is not None:
+                yield self._collect(s)
+
+    def close(self):
+        for e in self.engines:
+            e.close()
+        for p in self._pin_in + self._pin_out:
+            self._lib.sono_host_free(self._C.c_void_p(p))
+        self._pin_in, self._pin_out, self.engines = [], [], []
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()

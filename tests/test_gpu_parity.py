@@ -445,3 +445,25 @@ def test_fast_worker_features_and_host_table():
         eng.set_tables(None, c, s)
         b = eng.stft(x)
     assert np.abs(a.astype(int) - b.astype(int)).max() <= 1
+
+
+@pytest.mark.gpu
+def test_file_pipeline_matches_single_calls():
+    """The overlapped per-file batch path returns, file by file and in order, what sono_stft returns."""
+    from spectrogram_amd.sharding import FilePipeline
+    rng = np.random.default_rng(5)
+    files = []
+    for i in range(11):
+        L = int(rng.integers(1024 + 256 * 16, 1024 + 256 * 400))
+        x = (rng.standard_normal(L) * 0.2).astype(np.float32)
+        files.append(("f%d" % i, np.round(x * 32767).astype(np.int16)))
+    kw = dict(fft_n=1024, hop=256, window_id=F.WIN_WORKER_HANN, scale_mode=F.SCALE_WORKER_LOG5,
+              frame_rule=F.FRAMES_WORKER_COMPAT, twiddle_mode=F.TW_ACCURATE, arith=F.ARITH_FAST_F32, out_kind=F.OUT_RGBA8,
+              in_kind=F.IN_I16)
+    with E.Engine(**kw) as eng:
+        want = [eng.stft(x) for _, x in files]
+    with FilePipeline(max(len(x) for _, x in files), slots=3, **kw) as pipe:
+        got = list(pipe.run(files))
+    assert [t for t, _ in got] == [t for t, _ in files]
+    for (_, g), w in zip(got, want):
+        assert g.shape == w.shape and np.array_equal(g, w)
