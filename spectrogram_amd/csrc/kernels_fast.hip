@@ -32,6 +32,7 @@
 namespace sono {
 namespace fast1024 {
 
+constexpr int kNPoints = 1024;
 constexpr int kMaxWaves = 16;                      // independent wavefronts per workgroup (one workgroup per CU)
 constexpr int kPlaneStride = 36;                   // floats per transpose row: rows stay 16-B aligned and 16 consecutive
                                                    // rows start on 16 distinct 4-bank groups (ds_read_b128 conflict-free)
@@ -241,12 +242,13 @@ __device__ __forceinline__ void flush_quarter_store(const StftParams& p, const u
 // instead of exact roots of unity: the first pass reads its 31 factors as wave-uniform scalars, the
 // second pass reads factor 32*(g mod t) + lane of stage T = 32t from a [31][32] copy in LDS, and there
 // is no twiddle multiplication between the passes (it is part of those factors).
-constexpr int kOutU8 = 0, kOutRgba = 1, kOutFeatures = 2;
+// kOutDb / kOutMag: float32 20*log10(m) / m per bin, [frame][bin] (what the tolerance tests read).
+constexpr int kOutU8 = 0, kOutRgba = 1, kOutFeatures = 2, kOutDb = 3, kOutMag = 4;
 template <bool PLUGIN, typename In, int HOP32, int OUT, bool TABLE>
 __global__ __launch_bounds__(kMaxWaves * 64, 4) void stft1024_u8_kernel(StftParams p, FastScale fs,
                                                                         const float2* __restrict__ tw_table,
                                                                         uint8_t* __restrict__ tiles) {
-  constexpr bool RGBA = OUT == kOutRgba, FEAT = OUT == kOutFeatures;
+  constexpr bool RGBA = OUT == kOutRgba, FEAT = OUT == kOutFeatures, FLT = OUT == kOutDb || OUT == kOutMag;
   constexpr int kThreads = kMaxWaves * 64, kWaves = kMaxWaves;
   constexpr int kTileIters = RGBA ? kTileFrames / 4 : 1;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -440,6 +442,8 @@ __global__ __launch_bounds__(kMaxWaves * 64, 4) void stft1024_u8_kernel(StftPara
     // aligned 16-byte reads each.  Lane 0's registers sit one row off (k1 = 0), so it also supplies
     // mbuf[0] (Z[N - 256P] = Z[0] or Z[768]).
     const uint64_t row_a = (p.col0 + f0) * p.out_bins, row_b = row_a + p.out_bins;
+    // FLT: the pair separation leaves 2*X; the plugin's magnitude is 2/N * |X| (spectrogram.esm.js:195-198)
+    const float mag_scale = PLUGIN ? 1.0f / (float)kNPoints : 0.5f;
     float best_a = -1.0f, best_b = -1.0f;  // FEAT: this lane's largest |X|^2 so far and its bin
     int kbest_a = (int)p.bin_lo, kbest_b = (int)p.bin_lo;
 #pragma unroll
@@ -463,6 +467,7 @@ __global__ __launch_bounds__(kMaxWaves * 64, 4) void stft1024_u8_kernel(StftPara
         const float4 q01 = *reinterpret_cast<const float4*>(mbuf + idx);
         const float4 q23 = *reinterpret_cast<const float4*>(mbuf + idx + 2);
         uint32_t wa = 0, wb = 0;
+        float fa[4] = {0, 0, 0, 0}, fb[4] = {0, 0, 0, 0};
         const bool in_band = k >= (int)p.bin_lo && k < (int)p.bin_hi;
 #define SONO_BIN(B, ZR, ZI, PR, PI)                                          \
   {                                                                          \
@@ -473,6 +478,9 @@ __global__ __launch_bounds__(kMaxWaves * 64, 4) void stft1024_u8_kernel(StftPara
     if constexpr (FEAT) { /* a lane visits its bins in ascending order */    \
       if (in_band && ma > best_a) { best_a = ma; kbest_a = k + B; }          \
       if (in_band && mb > best_b) { best_b = mb; kbest_b = k + B; }          \
+    } else if constexpr (FLT) {                                              \
+      fa[B] = OUT == kOutDb ? fast_db(ma, fs) : __builtin_sqrtf(ma) * mag_scale; \
+      fb[B] = OUT == kOutDb ? fast_db(mb, fs) : __builtin_sqrtf(mb) * mag_scale; \
     } else {                                                                 \
       wa = put_index<PLUGIN, B>(ma, fs, wa);                                 \
       wb = put_index<PLUGIN, B>(mb, fs, wb);                                 \
@@ -486,6 +494,12 @@ __global__ __launch_bounds__(kMaxWaves * 64, 4) void stft1024_u8_kernel(StftPara
         if constexpr (RGBA) {
           wa2[g] = shifted ? wb : wa;  // an odd last frame was computed as B: it belongs in the A slot
           wb2[g] = wb;
+        } else if (FLT) {
+          if (in_band) {
+            float* o = reinterpret_cast<float*>(p.out) + (k - p.out_bin0);
+            if (st_a) *reinterpret_cast<float4*>(o + row_a) = make_float4(fa[0], fa[1], fa[2], fa[3]);
+            if (st_b) *reinterpret_cast<float4*>(o + row_b) = make_float4(fb[0], fb[1], fb[2], fb[3]);
+          }
         } else if (!FEAT && in_band) {
           const uint32_t col = k - p.out_bin0;
           if (st_a) *reinterpret_cast<uint32_t*>(out + row_a + col) = wa;
@@ -573,6 +587,11 @@ bool fast_u8_available(const StftParams& p) {
   return true;
 }
 
+bool fast_float_available(const StftParams& p) {
+  return fast_base_available(p) && !(p.bin_lo & 3) && !(p.bin_hi & 3) && !(p.out_bins & 3) && !(p.out_bin0 & 3) &&
+         !(reinterpret_cast<uintptr_t>(p.out) & 15);
+}
+
 bool fast_features_available(const StftParams& p) {
   return fast_base_available(p) && !(p.bin_lo & 3) && !(p.bin_hi & 3) && p.bin_lo < p.bin_hi;
 }
@@ -600,8 +619,11 @@ uint64_t fast_rgba_scratch_bytes() { return (uint64_t)cu_count() * 2 * fast1024:
 int launch_stft_fast(const StftParams& p, void* stream_v) {
   using namespace fast1024;
   const bool rgba = p.out_kind == SONO_OUT_RGBA8, feat = p.out_kind == SONO_OUT_FEATURES;
+  const bool flt = p.out_kind == SONO_OUT_F32_DB || p.out_kind == SONO_OUT_F32_MAG;
   if (rgba) {
     if (!fast_rgba_available(p) || !p.tile_scratch) return 1;
+  } else if (flt) {
+    if (!fast_float_available(p)) return 1;
   } else if (feat) {
     if (!fast_features_available(p)) return 1;
   } else {
@@ -639,6 +661,8 @@ int launch_stft_fast(const StftParams& p, void* stream_v) {
   do {                                                                                                      \
     if (rgba) SONO_LAUNCH_O(PLUGIN, In, H, kOutRgba);                                                       \
     else if (feat) SONO_LAUNCH_O(PLUGIN, In, H, kOutFeatures);                                              \
+    else if (p.out_kind == SONO_OUT_F32_DB) SONO_LAUNCH_O(PLUGIN, In, H, kOutDb);                           \
+    else if (p.out_kind == SONO_OUT_F32_MAG) SONO_LAUNCH_O(PLUGIN, In, H, kOutMag);                         \
     else SONO_LAUNCH_O(PLUGIN, In, H, kOutU8);                                                              \
   } while (0)
 #define SONO_LAUNCH(PLUGIN, In)                                                                             \
