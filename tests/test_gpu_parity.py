@@ -467,3 +467,52 @@ def test_file_pipeline_matches_single_calls():
     assert [t for t, _ in got] == [t for t, _ in files]
     for (_, g), w in zip(got, want):
         assert g.shape == w.shape and np.array_equal(g, w)
+
+
+@pytest.mark.gpu
+def test_full_size_worker_render_rgba_properties():
+    """The benchmark's own launch (1 h x 384 kHz, worker render to RGBA, fused image writer) on device
+    memory: (1) a signal with period 64*hop gives an image whose columns repeat every 64 frames;
+    (2) the image is the colour map applied to the colour indices the same kernel writes as uint8,
+    flipped and transposed, everywhere; (3) the first 64 columns are within 1 LSB of the CPU checker."""
+    torch = pytest.importorskip("torch")
+    n, hop, period_frames = 1024, 256, 64
+    period = hop * period_frames
+    L = 3600 * 384000
+    rng = np.random.default_rng(12)
+    base = (rng.standard_normal(period) * 0.1).astype(np.float32)
+    base[7000:9000] += (0.6 * np.sin(np.arange(2000) * 1.1)).astype(np.float32)
+    dev = torch.device("cuda:0")
+    x = torch.from_numpy(base).to(dev).repeat(L // period + 1)[:L].contiguous()
+    lut = (np.arange(1024, dtype=np.uint32) * 13 % 251).astype(np.uint8)
+    with worker_engine(n, hop, F.ARITH_FAST_F32, out_kind=F.OUT_RGBA8) as eng, \
+            worker_engine(n, hop, F.ARITH_FAST_F32, out_kind=F.OUT_U8_INDEX) as eng8:
+        eng.set_colormap(lut)
+        g = eng.geometry(L)
+        assert (g.width, g.frames, g.bins) == (5399996, 5399997, 512)       # (L-N) % hop == 0: one frame more than columns
+        img = torch.empty((g.bins, g.width, 4), dtype=torch.uint8, device=dev)
+        idx = torch.empty((g.frames, g.bins), dtype=torch.uint8, device=dev)
+        torch.cuda.synchronize()
+        eng.stft_device(x.data_ptr(), L, img.data_ptr(), img.numel())
+        eng8.stft_device(x.data_ptr(), L, idx.data_ptr(), idx.numel())
+        px = img.view(torch.int32).view(g.bins, g.width)                    # one int32 per pixel
+        # (1) periodic columns (column 0 is touched by the wrapped last frame: start at 64)
+        whole = (g.width // period_frames) * period_frames
+        v = px[:, period_frames:whole].view(g.bins, -1, period_frames)
+        assert bool((v == v[:, 0:1, :]).all())
+        # (2) image == LUT[indices], flipped and transposed, in chunks of 2^16 columns
+        lut32 = torch.from_numpy(lut.view(np.int32).copy()).to(dev)
+        for c0 in range(period_frames, g.width, 1 << 16):
+            c1 = min(g.width, c0 + (1 << 16))
+            want = lut32[idx[c0:c1].long()].t().flip(0)
+            assert bool((px[:, c0:c1] == want).all()), c0
+        # the wrapped frame (spectrogramWorker.js:40,59,79): column 0, one row down, bin 0 falls off the image
+        last = lut32[idx[g.width].long()]
+        assert bool((px[1:, 0] == last[1:].flip(0)).all()) and int(px[0, 0]) == int(lut32[idx[0, g.bins - 1].long()])
+        head = img[:, period_frames:2 * period_frames].cpu().numpy()
+    refi = oracle.worker_render(np.tile(base, 3)[:2 * period + n], n, 75.0, None)[..., 0].astype(np.int16)
+    l4 = lut.reshape(256, 4)
+    ok = np.zeros(head.shape[:2], bool)
+    for dlt in (-1, 0, 1):
+        ok |= np.all(head == l4[np.clip(refi[:, period_frames:2 * period_frames] + dlt, 0, 255)], axis=-1)
+    assert ok.all()
