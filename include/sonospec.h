@@ -171,6 +171,24 @@ int sono_geometry_for(uint32_t fft_n, uint32_t hop, uint32_t frame_rule, uint32_
 /* Source-row window of drawSpectrogram for scale 'linear' (spectrogram.esm.js:353-355,377-380):
  * rows [sy, sy+sh) of the flipped image, i.e. bins [bins-sy-sh, bins-sy).  fmax_hz == 0 = Nyquist. */
 int sono_plugin_crop(uint32_t bins, double sample_rate, double fmin_hz, double fmax_hz, int64_t* sy, int64_t* sh);
+
+/* The plugin's non-linear frequency scales (option `scale`), spectrogram.esm.js:412-478. */
+typedef enum sono_freq_scale {
+  SONO_FSCALE_LINEAR = 0,
+  SONO_FSCALE_MEL = 1,
+  SONO_FSCALE_LOGARITHMIC = 2,
+  SONO_FSCALE_BARK = 3,
+  SONO_FSCALE_ERB = 4
+} sono_freq_scale;
+double sono_hz_to_scale(uint32_t scale, double hz); /* hzToScale, :453-465 */
+double sono_scale_to_hz(uint32_t scale, double v);  /* scaleToHz, :466-478 */
+/* createFilterBank, :389-411: filter e has the two taps (bin[e], w0[e] = 1 - c) and (bin[e] + 1, w1[e] = c).
+ * The plugin uses filters == fft_n / 2 (:250-253). */
+int sono_filterbank_table(uint32_t scale, uint32_t fft_n, double sample_rate, uint32_t filters, int32_t* bin, double* w0,
+                          double* w1);
+/* drawSpectrogram's source-row window under a scale, :377-380 (scale 0 == sono_plugin_crop). */
+int sono_plugin_crop_scaled(uint32_t bins, double sample_rate, double fmin_hz, double fmax_hz, uint32_t scale, int64_t* sy,
+                            int64_t* sh);
 /* Colour LUTs: 256 RGBA doubles -> 1024 bytes.  Plugin rule spectrogram.esm.js:262-271, worker
  * rule spectrogramWorker.js:128-143 (NaN channel = absent). */
 int sono_plugin_lut(const double* colormap_rgba, uint8_t* lut_rgba);
@@ -213,6 +231,11 @@ int sono_set_tables(sono_ctx* ctx, const float* window /* fft_n */, const double
 
 /* ---- the transform ------------------------------------------------------------------------ */
 
+/* Installs (or, with bin == NULL, removes) the filter bank that getFrequencies applies between the magnitudes
+ * and the quantiser for a non-linear `scale` (applyFilterBank, spectrogram.esm.js:479-488,509-530): fft_n/2
+ * filters of two taps each, from sono_filterbank_table or from the host's own arithmetic.  Plugin scale mode
+ * only.  With a filter bank the transform runs in the general kernel. */
+int sono_set_filterbank(sono_ctx* ctx, const int32_t* bin, const double* w0, const double* w1);
 int sono_geometry_of(const sono_ctx* ctx, uint64_t n_samples, sono_geometry* out);
 /* Bytes sono_stft writes for n_samples under the context's out_kind. */
 uint64_t sono_out_bytes(const sono_ctx* ctx, uint64_t n_samples);

@@ -655,6 +655,46 @@ static napi_value js_pcm_to_device(napi_env env, napi_callback_info info) {
   return make_num(env, (double)frames);
 }
 
+/* setFilterbank(handle, Int32Array bin | null, Float64Array w0, Float64Array w1) */
+static napi_value js_set_filterbank(napi_env env, napi_callback_info info) {
+  ARGS(env, info, 2);
+  handle_t* h = get_handle(env, argv[0]);
+  if (!h) return NULL;
+  napi_typedarray_type t0, t1, t2;
+  void *b = NULL, *w0 = NULL, *w1 = NULL;
+  int64_t nb = ta_data(env, argv[1], &t0, &b);
+  if (nb < 0) return throw_msg(env, "setFilterbank(handle, Int32Array|null, Float64Array, Float64Array)");
+  if (!b) {
+    int rc = sono_set_filterbank(h->ctx, NULL, NULL, NULL);
+    return rc == SONO_OK ? NULL : throw_ctx(env, h, rc);
+  }
+  if (argc < 4) return throw_msg(env, "setFilterbank: weights missing");
+  int64_t n0 = ta_data(env, argv[2], &t1, &w0), n1 = ta_data(env, argv[3], &t2, &w1);
+  sono_config cfg;
+  sono_get_config(h->ctx, &cfg);
+  if (t0 != napi_int32_array || t1 != napi_float64_array || t2 != napi_float64_array || nb != (int64_t)cfg.fft_n / 2 || n0 != nb || n1 != nb)
+    return throw_msg(env, "setFilterbank: fft_n/2 entries of Int32Array, Float64Array, Float64Array");
+  int rc = sono_set_filterbank(h->ctx, (const int32_t*)b, (const double*)w0, (const double*)w1);
+  return rc == SONO_OK ? NULL : throw_ctx(env, h, rc);
+}
+
+/* pluginCropScaled(bins, sampleRate, fmin, fmax, scaleId) -> {sy, sh} */
+static napi_value js_plugin_crop_scaled(napi_env env, napi_callback_info info) {
+  ARGS(env, info, 5);
+  uint32_t bins, scale;
+  double sr, f0, f1;
+  if (!get_u32(env, argv[0], &bins) || !get_f64(env, argv[1], &sr) || !get_f64(env, argv[2], &f0) || !get_f64(env, argv[3], &f1) ||
+      !get_u32(env, argv[4], &scale))
+    return throw_msg(env, "pluginCropScaled(bins, sampleRate, fmin, fmax, scale)");
+  int64_t sy = 0, sh = 0;
+  if (sono_plugin_crop_scaled(bins, sr, f0, f1, scale, &sy, &sh) != SONO_OK) return throw_msg(env, "pluginCropScaled: bad arguments");
+  napi_value o;
+  napi_create_object(env, &o);
+  napi_set_named_property(env, o, "sy", make_num(env, (double)sy));
+  napi_set_named_property(env, o, "sh", make_num(env, (double)sh));
+  return o;
+}
+
 #define EXPORT(name, fn)                                                     \
   do {                                                                       \
     napi_value f_;                                                           \
@@ -690,6 +730,8 @@ static napi_value init(napi_env env, napi_value exports) {
   EXPORT("workerLut", js_worker_lut);
   EXPORT("windowTable", js_window_table);
   EXPORT("geometryFor", js_geometry_for);
+  EXPORT("setFilterbank", js_set_filterbank);
+  EXPORT("pluginCropScaled", js_plugin_crop_scaled);
   EXPORT("wavParse", js_wav_parse);
   EXPORT("wavGuano", js_wav_guano);
   EXPORT("guanoFields", js_guano_fields);

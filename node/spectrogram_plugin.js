@@ -6,6 +6,35 @@
 const S = require('./index.js');
 const N = S.native;
 
+// Non-linear frequency scales of the plugin (option `scale`), spectrogram.esm.js:389-478: a bank of
+// fftSamples/2 two-tap filters over [0, sampleRate/2], evaluated here with this V8's log10 / pow so that
+// the weights are the very doubles the reference computes.
+const SCALE_IDS = { linear: 0, mel: 1, logarithmic: 2, bark: 3, erb: 4 };
+const ERB_A = 1e3 * Math.log(10) / 107.939;                                         // :202
+const HZ_TO = {
+  mel: (t) => 2595 * Math.log10(1 + t / 700),
+  logarithmic: (t) => Math.log10(Math.max(1, t)),
+  bark: (t) => { let e = 26.81 * t / (1960 + t) - 0.53; if (e < 2) e += 0.15 * (2 - e); if (e > 20.1) e += 0.22 * (e - 20.1); return e; },
+  erb: (t) => ERB_A * Math.log10(1 + 0.00437 * t),
+};
+const TO_HZ = {
+  mel: (t) => 700 * (Math.pow(10, t / 2595) - 1),
+  logarithmic: (t) => Math.pow(10, t),
+  bark: (t) => { if (t < 2) t = (t - 0.3) / 0.85; if (t > 20.1) t = (t + 4.422) / 1.22; return (t + 0.53) / (26.28 - t) * 1960; },
+  erb: (t) => (Math.pow(10, t / ERB_A) - 1) / 0.00437,
+};
+function filterBank(scale, n, sampleRate) {
+  const filters = n / 2, toScale = HZ_TO[scale], toHz = TO_HZ[scale];
+  const lo = toScale(0), hi = toScale(sampleRate / 2), h = sampleRate / n;
+  const bin = new Int32Array(filters), w0 = new Float64Array(filters), w1 = new Float64Array(filters);
+  for (let e = 0; e < filters; e++) {                                               // :401-408
+    const s = toHz(lo + e / filters * (hi - lo));
+    const o = Math.floor(s / h), l = o * h, c = (s - l) / ((o + 1) * h - l);
+    bin[e] = o; w0[e] = 1 - c; w1[e] = c;
+  }
+  return { bin, w0, w1 };
+}
+
 class Spectrogram {
   static create(options) { return new Spectrogram(options || {}); }
 
@@ -55,8 +84,10 @@ class Spectrogram {
     this.buffer = null;
   }
 
-  _engine(hop) {
-    const key = [this.fftSamples, hop, this.windowFunc, this.alpha, this.gainDB, this.rangeDB, this.arith].join(':');
+  _engine(hop, sampleRate) {
+    if (!(this.scale in SCALE_IDS)) throw new Error("unknown scale '" + this.scale + "'");
+    const fbRate = this.scale !== 'linear' && sampleRate ? sampleRate : 0;
+    const key = [this.fftSamples, hop, this.windowFunc, this.alpha, this.gainDB, this.rangeDB, this.arith, this.scale, fbRate].join(':');
     let h = this._engines.get(key);
     if (!h) {
       const n = this.fftSamples;
@@ -74,6 +105,10 @@ class Spectrogram {
         N.setTables(h, null, tw.cos, tw.sin);
       }
       N.setColormap(h, this._colorMapUint);
+      if (fbRate) {                         // :509-521, with this V8's own log10 / pow
+        const fb = filterBank(this.scale, n, fbRate);
+        N.setFilterbank(h, fb.bin, fb.w0, fb.w1);
+      }
       this._engines.set(key, h);
     }
     return h;
@@ -84,11 +119,9 @@ class Spectrogram {
     return this._engine(this.fftSamples);
   }
 
-  // :492-542 with scale 'linear': Array[channels] of Array[frames] of Uint8Array(fftSamples/2)
+  // :492-542: Array[channels] of Array[frames] of Uint8Array(fftSamples/2)
   getFrequencies(t) {
     if (!t) return;
-    if (this.scale !== 'linear')
-      throw new Error("scale '" + this.scale + "': only 'linear' (what SonoRadar's wsManager passes) runs on the GPU");
     const r = this.fftSamples;
     const channels = this.options.splitChannels ? t.numberOfChannels : 1;            // :495
     this.frequencyMax = this.frequencyMax || t.sampleRate / 2;                       // :496
@@ -96,7 +129,7 @@ class Spectrogram {
     const noverlap = N.pluginNoverlap(r, this.noverlap || 0, t.length, this.canvasWidth);   // :502-506
     const hop = r - noverlap;
     if (hop <= 0) throw new Error('noverlap must be smaller than fftSamples');
-    const h = this._engine(hop);
+    const h = this._engine(hop, t.sampleRate);
     const out = [];
     for (let ch = 0; ch < channels; ch++) {
       const flat = N.stft(h, t.getChannelData(ch));
@@ -133,7 +166,7 @@ class Spectrogram {
     const h = this._anyEngine();
     N.setColormap(h, this._colorMapUint);
     const data = N.colorize(h, cols.flat || new Uint8Array(0), width, B, 0, B);
-    const crop = N.pluginCrop(B, this.buffer.sampleRate, this.frequencyMin, this.frequencyMax);   // :377-380
+    const crop = N.pluginCropScaled(B, this.buffer.sampleRate, this.frequencyMin, this.frequencyMax, SCALE_IDS[this.scale]);   // :377-380
     return { width, height: B, data, crop };
   }
 

@@ -36,6 +36,10 @@ for (const r of cases('plugin_crop_grid')[0].rows) {
   const c = S.native.pluginCrop(r.N / 2, r.sr, r.fmin, r.fmax);
   ok(c.sy === r.sy && c.sh === r.sh, 'crop ' + JSON.stringify(r));
 }
+for (const r of cases('plugin_scale_crop_grid')[0].rows) {
+  const c = S.native.pluginCropScaled(r.N / 2, r.sr, r.fmin, r.fmax, { mel: 1, logarithmic: 2, bark: 3, erb: 4 }[r.scale]);
+  ok(c.sy === r.sy && c.sh === r.sh, 'scaled crop ' + JSON.stringify(r));
+}
 for (const c of cases('plugin_render')) {
   if (c.colormap !== 'default' && c.colormap !== 'rainbow') continue;
   const p = Spectrogram.create({ colorMap: colormap(c.colormap) });
@@ -161,6 +165,22 @@ if (!cpuOnly) {
     ok(img.width === c.image_width && img.height === c.image_height && equal(img.data, load(c.rgba, Uint8Array)), 'plugin render ' + c.id);
     ok(img.crop.sy === c.crop.sy && img.crop.sh === c.crop.sh, 'plugin crop ' + c.id);
     p.destroy();
+  }
+  // non-linear frequency scales: exact arithmetic with this V8's filter weights reproduces the reference's bytes
+  for (const c of cases('plugin_scale_frequencies')) {
+    const sr = manifest.signals[c.signal].sample_rate;
+    const ref = load(c.data, Uint8Array);
+    for (const arith of ['exact', 'fast']) {
+      const p = Spectrogram.create({ fftSamples: c.N, noverlap: c.noverlap, colorMap: 'gray', scale: c.scale, arith });
+      const out = p.getFrequencies(audioBuffer(signal(c.signal), sr))[0];
+      if (arith === 'exact') ok(equal(out.flat, ref), 'scale ' + c.scale + ' exact ' + c.id);
+      else {
+        let worst = 0;
+        for (let i = 0; i < ref.length; i++) { let d = Math.abs(out.flat[i] - ref[i]); d = Math.min(d, 256 - d); if (d > worst) worst = d; }
+        ok(worst <= 1, 'scale ' + c.scale + ' fast ' + c.id + ' worst ' + worst);
+      }
+      p.destroy();
+    }
   }
   // render before init is dropped; setOptions installs the colour map
   {

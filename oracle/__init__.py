@@ -146,6 +146,50 @@ def plugin_get_frequencies(x, n, noverlap=None, canvas_width=300, window="hann",
     return out
 
 
+SCALE_IDS = {"linear": 0, "mel": 1, "logarithmic": 2, "bark": 3, "erb": 4}
+
+
+def hz_to_scale(scale, hz):
+    L = lib()
+    L.orc_hz_to_scale.restype = C.c_double
+    return L.orc_hz_to_scale(SCALE_IDS[scale], C.c_double(hz))
+
+
+def scale_to_hz(scale, v):
+    L = lib()
+    L.orc_scale_to_hz.restype = C.c_double
+    return L.orc_scale_to_hz(SCALE_IDS[scale], C.c_double(v))
+
+
+def plugin_filterbank(scale, n, sample_rate):
+    b, w0, w1 = np.empty(n // 2, np.int32), np.empty(n // 2, np.float64), np.empty(n // 2, np.float64)
+    lib().orc_plugin_filterbank(SCALE_IDS[scale], n, C.c_double(sample_rate), n // 2, _p(b, C.c_int32), _p(w0, C.c_double),
+                                _p(w1, C.c_double))
+    return b, w0, w1
+
+
+def plugin_get_frequencies_scaled(x, n, noverlap, scale, sample_rate, canvas_width=300, window="hann", alpha=None,
+                                  gain_db=20.0, range_db=80.0):
+    x = _f32(x)
+    L = lib()
+    ov = L.orc_plugin_noverlap(n, int(noverlap or 0), x.shape[0], canvas_width)
+    frames = L.orc_plugin_frame_count(x.shape[0], n, n - ov)
+    out = np.empty((frames, n // 2), np.uint8)
+    L.orc_plugin_get_frequencies_scaled.restype = C.c_size_t
+    got = L.orc_plugin_get_frequencies_scaled(_p(x, C.c_float), C.c_size_t(x.shape[0]), n, int(noverlap or 0), canvas_width,
+                                              WINDOW_IDS[window], C.c_double(float(alpha) if alpha else 0.0), C.c_double(gain_db),
+                                              C.c_double(range_db), SCALE_IDS[scale], C.c_double(sample_rate), _p(out, C.c_uint8))
+    assert got == frames, (got, frames)
+    return out
+
+
+def plugin_crop_scaled(bins, sample_rate, fmin, fmax, scale):
+    sy, sh = C.c_long(0), C.c_long(0)
+    lib().orc_plugin_crop_scaled(bins, C.c_double(sample_rate), C.c_double(fmin), C.c_double(fmax), SCALE_IDS[scale],
+                                 C.byref(sy), C.byref(sh))
+    return sy.value, sh.value
+
+
 def plugin_resample(frames, out_width):
     frames = np.ascontiguousarray(frames, np.uint8)
     F, B = frames.shape

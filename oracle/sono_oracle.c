@@ -221,6 +221,90 @@ size_t orc_plugin_get_frequencies(const float *x, size_t length, int n, int nove
   return f;
 }
 
+/* ---- non-linear frequency scales ------------------------------------------------------------ */
+
+static const double ERB_A = 1e3 * 2.302585092994046 / 107.939; /* :202, 1e3 * Math.log(10) / 107.939 */
+
+double orc_hz_to_scale(int scale, double t) { /* :412-465 */
+  switch (scale) {
+    case 1: return 2595 * log10(1 + t / 700);
+    case 2: return log10(t > 1 ? t : 1);
+    case 3: {
+      double e = 26.81 * t / (1960 + t) - .53;
+      if (e < 2) e += .15 * (2 - e);
+      if (e > 20.1) e += .22 * (e - 20.1);
+      return e;
+    }
+    case 4: return ERB_A * log10(1 + .00437 * t);
+  }
+  return t;
+}
+
+double orc_scale_to_hz(int scale, double t) { /* :415-478 */
+  switch (scale) {
+    case 1: return 700 * (pow(10, t / 2595) - 1);
+    case 2: return pow(10, t);
+    case 3:
+      if (t < 2) t = (t - .3) / .85;
+      if (t > 20.1) t = (t + 4.422) / 1.22;
+      return (t + .53) / (26.28 - t) * 1960;
+    case 4: return (pow(10, t / ERB_A) - 1) / .00437;
+  }
+  return t;
+}
+
+void orc_plugin_filterbank(int scale, int n, double sr, int filters, int32_t *bin, double *w0, double *w1) {
+  const double i = orc_hz_to_scale(scale, 0), a = orc_hz_to_scale(scale, sr / 2), h = sr / n; /* :395-400 */
+  for (int e = 0; e < filters; e++) {
+    const double s = orc_scale_to_hz(scale, i + (double)e / filters * (a - i)); /* :402-407 */
+    const double o = floor(s / h), l = o * h, c = (s - l) / ((o + 1) * h - l);
+    bin[e] = (int32_t)o;
+    w0[e] = 1 - c;
+    w1[e] = c;
+  }
+}
+
+void orc_plugin_apply_filterbank(const float *mag, int bins, const int32_t *bin, const double *w0,
+                                 const double *w1, int filters, float *out) {
+  /* :484-486: r[i] += t[s] * e[i][s] over EVERY s, accumulated in a Float32Array.  The rows are zero
+   * outside their two taps, so the other terms add t[s] * 0: nothing, unless some t[s] is NaN or
+   * infinite, in which case every output of the frame becomes NaN. */
+  int bad = 0;
+  for (int s = 0; s < bins; s++)
+    if (!isfinite(mag[s])) bad = 1;
+  for (int i = 0; i < filters; i++) {
+    float r = 0;
+    const int o = bin[i];
+    if (o >= 0 && o < bins) r = (float)((double)r + (double)mag[o] * w0[i]);
+    if (o + 1 >= 0 && o + 1 < bins) r = (float)((double)r + (double)mag[o + 1] * w1[i]);
+    out[i] = bad ? NAN : r;
+  }
+}
+
+size_t orc_plugin_get_frequencies_scaled(const float *x, size_t length, int n, int noverlap,
+                                         int canvas_width, int window_id, double alpha, double gain,
+                                         double range, int scale, double sample_rate, uint8_t *out) {
+  if (scale == 0)
+    return orc_plugin_get_frequencies(x, length, n, noverlap, canvas_width, window_id, alpha, gain, range, out, NULL, NULL, NULL);
+  const int bins = n / 2;
+  const int ov = orc_plugin_noverlap(n, noverlap, length, canvas_width);
+  const int hop = n - ov;
+  if (!is_pow2(n) || hop <= 0) return (size_t)-1;
+  const size_t frames = orc_plugin_frame_count(length, n, hop);
+  float *mags = (float *)malloc(sizeof(float) * (frames ? frames : 1) * (size_t)bins);
+  const size_t got = orc_plugin_get_frequencies(x, length, n, noverlap, canvas_width, window_id, alpha, gain, range, NULL, mags, NULL, NULL);
+  int32_t *bin = (int32_t *)malloc(sizeof(int32_t) * (size_t)bins);
+  double *w0 = (double *)malloc(sizeof(double) * (size_t)bins), *w1 = (double *)malloc(sizeof(double) * (size_t)bins);
+  float *flt = (float *)malloc(sizeof(float) * (size_t)bins);
+  orc_plugin_filterbank(scale, n, sample_rate, bins, bin, w0, w1); /* numMelFilters = fftSamples / 2, :250-253 */
+  for (size_t f = 0; f < got && got != (size_t)-1; f++) {
+    orc_plugin_apply_filterbank(mags + f * (size_t)bins, bins, bin, w0, w1, bins, flt);
+    for (int t = 0; t < bins; t++) out[f * (size_t)bins + (size_t)t] = plugin_quantise(flt[t], gain, range);
+  }
+  free(mags); free(bin); free(w0); free(w1); free(flt);
+  return got;
+}
+
 /* :595-640.  The reference scans every input frame for every output column; only frames whose
  * interval can touch the column are visited here (two frames of margin on both sides), with the
  * reference's own expressions deciding membership and weight, in the same ascending order. */
@@ -261,6 +345,16 @@ void orc_plugin_crop(int bins, double sample_rate, double fmin, double fmax, lon
   const double nyq = sample_rate / 2;
   if (fmax == 0) fmax = nyq; /* :496 */
   const double u = fmin / nyq, f = fmax / nyq;
+  const double p = f < 1 ? f : 1;
+  *sy = (long)js_round((double)bins * (1 - p));
+  *sh = (long)js_round((double)bins * (p - u));
+}
+
+void orc_plugin_crop_scaled(int bins, double sample_rate, double fmin, double fmax, int scale, long *sy, long *sh) {
+  const double nyq = sample_rate / 2;
+  if (fmax == 0) fmax = nyq; /* :496 */
+  const double u = orc_hz_to_scale(scale, fmin) / orc_hz_to_scale(scale, nyq); /* :377-379 */
+  const double f = orc_hz_to_scale(scale, fmax) / orc_hz_to_scale(scale, nyq);
   const double p = f < 1 ? f : 1;
   *sy = (long)js_round((double)bins * (1 - p));
   *sh = (long)js_round((double)bins * (p - u));

@@ -87,6 +87,24 @@ void orc_plugin_lut(const double *colormap_rgba, uint8_t *lut);
 void orc_plugin_crop(int bins, double sample_rate, double fmin_hz, double fmax_hz, long *sy,
                      long *sh);
 
+/* Non-linear frequency scales, spectrogram.esm.js:412-478.  scale: 0 linear, 1 mel, 2 logarithmic,
+ * 3 bark, 4 erb. */
+double orc_hz_to_scale(int scale, double hz);
+double orc_scale_to_hz(int scale, double v);
+/* createFilterBank, :389-411: row e has the taps (bin[e], 1 - c) and (bin[e] + 1, c). */
+void orc_plugin_filterbank(int scale, int n, double sample_rate, int filters, int32_t *bin, double *w0,
+                           double *w1);
+/* applyFilterBank, :479-488, on one frame of n/2 magnitudes: a float32 accumulator over every bin. */
+void orc_plugin_apply_filterbank(const float *mag, int bins, const int32_t *bin, const double *w0,
+                                 const double *w1, int filters, float *out);
+/* getFrequencies with `scale` (:509-530); scale 0 equals orc_plugin_get_frequencies. */
+size_t orc_plugin_get_frequencies_scaled(const float *x, size_t length, int n, int noverlap,
+                                         int canvas_width, int window_id, double alpha, double gain_db,
+                                         double range_db, int scale, double sample_rate, uint8_t *out);
+/* crop window of drawSpectrogram under a scale, :377-380. */
+void orc_plugin_crop_scaled(int bins, double sample_rate, double fmin_hz, double fmax_hz, int scale,
+                            long *sy, long *sh);
+
 /* LUT + vertical flip of drawSpectrogram, :366-376.  frames: width x bins uint8 ->
  * rgba: bins rows x width columns x 4, row 0 = highest bin. */
 void orc_plugin_draw(const uint8_t *frames, size_t width, int bins, const uint8_t *lut,

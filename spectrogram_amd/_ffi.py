@@ -27,6 +27,7 @@ ARITH_FAST_F32, ARITH_EXACT_F64 = 0, 1
 OUT_U8_INDEX, OUT_RGBA8, OUT_F32_DB, OUT_F32_MAG, OUT_FEATURES = 0, 1, 2, 3, 4
 IN_F32, IN_I16 = 0, 1
 MEM_HOST, MEM_DEVICE = 0, 1
+FREQ_SCALES = {"linear": 0, "mel": 1, "logarithmic": 2, "bark": 3, "erb": 4}
 
 
 class SonoConfig(C.Structure):
@@ -65,6 +66,12 @@ class SonoGeometry(C.Structure):
 # every symbol include/sonospec.h declares: name -> (restype, argtypes)
 _VP = C.c_void_p
 SYMBOLS = {
+    "sono_hz_to_scale": (C.c_double, [C.c_uint32, C.c_double]),
+    "sono_scale_to_hz": (C.c_double, [C.c_uint32, C.c_double]),
+    "sono_filterbank_table": (C.c_int, [C.c_uint32, C.c_uint32, C.c_double, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "sono_plugin_crop_scaled": (C.c_int, [C.c_uint32, C.c_double, C.c_double, C.c_double, C.c_uint32, C.POINTER(C.c_int64),
+                                          C.POINTER(C.c_int64)]),
+    "sono_set_filterbank": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "sono_stft_host_async": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64]),
     "sono_host_malloc": (C.c_void_p, [C.c_uint64]),
     "sono_host_free": (C.c_int, [C.c_void_p]),

@@ -28,6 +28,8 @@ struct sono_ctx {
   uint32_t* d_lut = nullptr;  // 256 packed pixels
   void* d_fast = nullptr;     // twiddle matrix of the fast kernel (accurate twiddles only)
   bool have_lut = false;
+  int32_t* d_fb_bin = nullptr;  // filter bank of a non-linear frequency scale (fft_n/2 entries each), or nullptr
+  double* d_fb_w = nullptr;     // w0 then w1
   bool host_twiddles = false;  // sono_set_tables replaced the twiddle table
   // host copies (sono_set_tables may replace part of them)
   std::vector<float> h_window;
@@ -213,7 +215,7 @@ void sono_destroy(sono_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
-  void* bufs[] = {c->d_window, c->d_tw, c->d_lut, c->d_fast, c->d_in, c->d_out, c->d_aux};
+  void* bufs[] = {c->d_window, c->d_tw, c->d_lut, c->d_fast, c->d_in, c->d_out, c->d_aux, c->d_fb_bin, c->d_fb_w};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
   if (c->ev_start) (void)hipEventDestroy(c->ev_start);
@@ -263,6 +265,28 @@ int sono_set_tables(sono_ctx* c, const float* window, const double* tw_cos, cons
   return upload_tables(c);
 }
 
+int sono_set_filterbank(sono_ctx* c, const int32_t* bin, const double* w0, const double* w1) {
+  if (!c) return SONO_ERR_ARG;
+  HIP_TRY(c, hipSetDevice(c->device));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  if (!bin) {
+    if (c->d_fb_bin) HIP_TRY(c, hipFree(c->d_fb_bin));
+    if (c->d_fb_w) HIP_TRY(c, hipFree(c->d_fb_w));
+    c->d_fb_bin = nullptr;
+    c->d_fb_w = nullptr;
+    return SONO_OK;
+  }
+  if (!w0 || !w1) return fail(c, SONO_ERR_ARG, "filter bank weights missing");
+  if (c->cfg.scale_mode != SONO_SCALE_PLUGIN_DB) return fail(c, SONO_ERR_ARG, "a filter bank needs the plugin scale mode");
+  const uint32_t half = c->cfg.fft_n / 2;
+  if (!c->d_fb_bin) HIP_TRY(c, hipMalloc((void**)&c->d_fb_bin, sizeof(int32_t) * half));
+  if (!c->d_fb_w) HIP_TRY(c, hipMalloc((void**)&c->d_fb_w, sizeof(double) * 2 * half));
+  HIP_TRY(c, hipMemcpy(c->d_fb_bin, bin, sizeof(int32_t) * half, hipMemcpyHostToDevice));
+  HIP_TRY(c, hipMemcpy(c->d_fb_w, w0, sizeof(double) * half, hipMemcpyHostToDevice));
+  HIP_TRY(c, hipMemcpy(c->d_fb_w + half, w1, sizeof(double) * half, hipMemcpyHostToDevice));
+  return SONO_OK;
+}
+
 int sono_geometry_of(const sono_ctx* c, uint64_t L, sono_geometry* out) {
   if (!c || !out) return SONO_ERR_ARG;
   return compute_geometry(c->cfg.fft_n, c->cfg.hop, c->cfg.frame_rule, c->bin_lo, c->bin_hi, L, out);
@@ -283,7 +307,7 @@ static uint64_t in_bytes(const sono_ctx* c, uint64_t L) { return L * (c->cfg.in_
 
 // Which flavour of the fast 1024-point kernel serves this context (StftParams::fast_mode).
 static uint32_t fast_mode_of(const sono_ctx* c) {
-  if (c->cfg.arith != SONO_ARITH_FAST_F32 || c->cfg.fft_n != 1024) return 0;
+  if (c->cfg.arith != SONO_ARITH_FAST_F32 || c->cfg.fft_n != 1024 || c->d_fb_bin) return 0;
   if (c->cfg.twiddle_mode == SONO_TW_ACCURATE && !c->host_twiddles) return c->d_fast ? 1 : 0;
   // table twiddles: the kernel folds the first butterfly of every stage, so that factor must be 1
   for (uint32_t T = 1; T < c->cfg.fft_n; T <<= 1)
@@ -293,7 +317,8 @@ static uint32_t fast_mode_of(const sono_ctx* c) {
 static bool fast_eligible(const sono_ctx* c) { return fast_mode_of(c) != 0; }
 // The 2048/4096-point kernel takes any twiddle table whose stages start with the factor (1, 0).
 static bool mw_eligible(const sono_ctx* c) {
-  if (c->cfg.arith != SONO_ARITH_FAST_F32 || (c->cfg.fft_n != 512 && c->cfg.fft_n != 2048 && c->cfg.fft_n != 4096)) return false;
+  if (c->cfg.arith != SONO_ARITH_FAST_F32 || (c->cfg.fft_n != 512 && c->cfg.fft_n != 2048 && c->cfg.fft_n != 4096) || c->d_fb_bin)
+    return false;
   for (uint32_t T = 1; T < c->cfg.fft_n; T <<= 1)
     if (c->h_cos[T - 1] != 1.0 || c->h_sin[T - 1] != 0.0) return false;
   return true;
@@ -329,6 +354,9 @@ int sono_stft_async(sono_ctx* c, const void* pcm, uint64_t L, void* out, uint64_
   p.fast_table = c->d_fast;
   p.fast_mode = fast_mode_of(c);
   p.mw_ok = mw_eligible(c) ? 1u : 0u;
+  p.fb_bin = c->d_fb_bin;
+  p.fb_w0 = c->d_fb_w;
+  p.fb_w1 = c->d_fb_w ? c->d_fb_w + n / 2 : nullptr;
   p.tile_scratch = nullptr;
   p.scale_mode = c->cfg.scale_mode;
   p.out_kind = c->cfg.out_kind;

@@ -186,6 +186,64 @@ int sono_plugin_crop(uint32_t bins, double sample_rate, double fmin, double fmax
   return SONO_OK;
 }
 
+// ---- non-linear frequency scales, spectrogram.esm.js:412-478 (erb constant :202)
+static const double kErbA = 1e3 * std::log(10.0) / 107.939;
+
+double sono_hz_to_scale(uint32_t scale, double t) {
+  switch (scale) {
+    case SONO_FSCALE_MEL: return 2595 * std::log10(1 + t / 700);
+    case SONO_FSCALE_LOGARITHMIC: return std::log10(t > 1 ? t : 1);
+    case SONO_FSCALE_BARK: {
+      double e = 26.81 * t / (1960 + t) - .53;
+      if (e < 2) e += .15 * (2 - e);
+      if (e > 20.1) e += .22 * (e - 20.1);
+      return e;
+    }
+    case SONO_FSCALE_ERB: return kErbA * std::log10(1 + .00437 * t);
+    default: return t;
+  }
+}
+
+double sono_scale_to_hz(uint32_t scale, double t) {
+  switch (scale) {
+    case SONO_FSCALE_MEL: return 700 * (std::pow(10.0, t / 2595) - 1);
+    case SONO_FSCALE_LOGARITHMIC: return std::pow(10.0, t);
+    case SONO_FSCALE_BARK:
+      if (t < 2) t = (t - .3) / .85;
+      if (t > 20.1) t = (t + 4.422) / 1.22;
+      return (t + .53) / (26.28 - t) * 1960;
+    case SONO_FSCALE_ERB: return (std::pow(10.0, t / kErbA) - 1) / .00437;
+    default: return t;
+  }
+}
+
+int sono_filterbank_table(uint32_t scale, uint32_t fft_n, double sample_rate, uint32_t filters, int32_t* bin, double* w0, double* w1) {
+  if (!bin || !w0 || !w1 || scale > SONO_FSCALE_ERB || scale == SONO_FSCALE_LINEAR || !sono::is_pow2(fft_n) || !(sample_rate > 0) || !filters)
+    return SONO_ERR_ARG;
+  // createFilterBank, spectrogram.esm.js:395-408
+  const double i = sono_hz_to_scale(scale, 0), a = sono_hz_to_scale(scale, sample_rate / 2), h = sample_rate / fft_n;
+  for (uint32_t e = 0; e < filters; e++) {
+    const double s = sono_scale_to_hz(scale, i + (double)e / filters * (a - i));
+    const double o = std::floor(s / h), l = o * h, c = (s - l) / ((o + 1) * h - l);
+    bin[e] = (int32_t)o;
+    w0[e] = 1 - c;
+    w1[e] = c;
+  }
+  return SONO_OK;
+}
+
+int sono_plugin_crop_scaled(uint32_t bins, double sample_rate, double fmin, double fmax, uint32_t scale, int64_t* sy, int64_t* sh) {
+  if (!sy || !sh || !(sample_rate > 0) || scale > SONO_FSCALE_ERB) return SONO_ERR_ARG;
+  const double nyq = sample_rate / 2;
+  if (fmax == 0) fmax = nyq;
+  const double u = sono_hz_to_scale(scale, fmin) / sono_hz_to_scale(scale, nyq);  // :377-379
+  const double f = sono_hz_to_scale(scale, fmax) / sono_hz_to_scale(scale, nyq);
+  const double p = f < 1 ? f : 1;
+  *sy = (int64_t)ecma_round((double)bins * (1 - p));
+  *sh = (int64_t)ecma_round((double)bins * (p - u));
+  return SONO_OK;
+}
+
 int sono_plugin_lut(const double* cm, uint8_t* lut) {  // spectrogram.esm.js:262-271
   if (!cm || !lut) return SONO_ERR_ARG;
   for (int i = 0; i < 1024; i++) lut[i] = ecma_uint8_clamp(ecma_round(255 * cm[i]));

@@ -47,6 +47,17 @@ __device__ __forceinline__ float load_sample<int16_t>(const int16_t* x, uint64_t
   return (float)x[i] * (1.0f / 32768.0f);
 }
 
+// colour index of a filter-bank output m (already the reference's float32 magnitude)
+template <typename A>
+__device__ __forceinline__ uint32_t fb_index(float m, const StftParams& p, const FastScale& fs, double two_over_n) {
+  if constexpr (sizeof(A) == 8) {
+    return plugin_index_exact(m, p.gain_db, p.range_db);
+  } else {
+    const float x = m * (float)(1.0 / two_over_n);  // fast_index takes |X|^2 before the 2/N scaling
+    return fast_index(x * x, fs);
+  }
+}
+
 template <typename A /* float | double */, typename In>
 __global__ __launch_bounds__(kThreads) void stft_general_kernel(StftParams p, FastScale fs, uint32_t frames_per_block,
                                                                uint32_t tile_stride) {
@@ -54,6 +65,8 @@ __global__ __launch_bounds__(kThreads) void stft_general_kernel(StftParams p, Fa
   float* re = reinterpret_cast<float*>(smem);
   float* im = re + p.n;
   unsigned char* tile = reinterpret_cast<unsigned char*>(im + p.n);  // [frames_per_block][tile_stride]
+  float* fb_mag = reinterpret_cast<float*>(tile + (size_t)frames_per_block * tile_stride);  // [n/2], filter-bank mode only
+  const bool fb = p.fb_bin != nullptr;  // non-linear frequency scale: re[y] holds the filtered magnitude after the FFT
 
   using TW = typename Tw2<A>::type;
   const TW* __restrict__ tw = reinterpret_cast<const TW*>(p.twiddles);
@@ -93,6 +106,35 @@ __global__ __launch_bounds__(kThreads) void stft_general_kernel(StftParams p, Fa
       }
     }
     __syncthreads();
+    if (fb) {
+      // applyFilterBank, spectrogram.esm.js:479-488: out[i] = sum over EVERY bin s of mag[s] * bank[i][s] in a
+      // Float32Array accumulator.  A row is zero outside its two taps (fb_bin[i], fb_bin[i] + 1), so the sum is
+      // float32(float32(mag[o] * w0) + mag[o+1] * w1) -- unless some magnitude of the frame is NaN or infinite:
+      // then mag[s] * 0 is NaN for that s and every output of the frame is NaN.
+      int bad = 0;
+      for (uint32_t y = tid; y < half; y += kThreads) {
+        const float r = re[y], i = im[y];
+        float m;
+        if constexpr (sizeof(A) == 8) m = plugin_mag_exact(r, i, two_over_n);
+        else m = sqrtf(r * r + i * i) * (float)two_over_n;
+        fb_mag[y] = m;
+        bad |= !isfinite(m);
+      }
+      bad = __syncthreads_or(bad);
+      for (uint32_t y = tid; y < half; y += kThreads) {
+        const int32_t o = p.fb_bin[y];
+        float acc = 0.0f;
+        if constexpr (sizeof(A) == 8) {
+          if (o >= 0 && o < (int32_t)half) acc = (float)((double)acc + (double)fb_mag[o] * p.fb_w0[y]);
+          if (o + 1 >= 0 && o + 1 < (int32_t)half) acc = (float)((double)acc + (double)fb_mag[o + 1] * p.fb_w1[y]);
+        } else {
+          if (o >= 0 && o < (int32_t)half) acc = fb_mag[o] * (float)p.fb_w0[y];
+          if (o + 1 >= 0 && o + 1 < (int32_t)half) acc += fb_mag[o + 1] * (float)p.fb_w1[y];
+        }
+        re[y] = bad ? __builtin_nanf("") : acc;
+      }
+      __syncthreads();
+    }
     if (p.out_kind == SONO_OUT_FEATURES) {
       // per-frame peak: first bin whose float32 magnitude exceeds all earlier ones (strict >)
       float best_m = -1.0f;
@@ -100,7 +142,9 @@ __global__ __launch_bounds__(kThreads) void stft_general_kernel(StftParams p, Fa
       for (uint32_t y = p.bin_lo + tid; y < p.bin_hi; y += kThreads) {
         const float r = re[y], i = im[y];
         float m;
-        if constexpr (sizeof(A) == 8) {
+        if (fb) {
+          m = r;
+        } else if constexpr (sizeof(A) == 8) {
           const double e = r, s = i;
           const double mag = sqrt(e * e + s * s);
           m = (p.scale_mode == SONO_SCALE_WORKER_LOG5) ? (float)mag : (float)(two_over_n * mag);
@@ -132,7 +176,9 @@ __global__ __launch_bounds__(kThreads) void stft_general_kernel(StftParams p, Fa
         const uint32_t k = red_k[0];
         const float r = re[k], i = im[k];
         uint32_t idx;
-        if constexpr (sizeof(A) == 8) {
+        if (fb) {
+          idx = fb_index<A>(r, p, fs, two_over_n);
+        } else if constexpr (sizeof(A) == 8) {
           idx = (p.scale_mode == SONO_SCALE_WORKER_LOG5)
                     ? worker_index_exact(r, i)
                     : plugin_index_exact(plugin_mag_exact(r, i, two_over_n), p.gain_db, p.range_db);
@@ -152,7 +198,9 @@ __global__ __launch_bounds__(kThreads) void stft_general_kernel(StftParams p, Fa
       const float r = re[y], i = im[y];
       if (p.out_kind == SONO_OUT_U8_INDEX || p.out_kind == SONO_OUT_RGBA8) {
         uint32_t idx;
-        if constexpr (sizeof(A) == 8) {
+        if (fb) {
+          idx = fb_index<A>(r, p, fs, two_over_n);
+        } else if constexpr (sizeof(A) == 8) {
           idx = (p.scale_mode == SONO_SCALE_WORKER_LOG5)
                     ? worker_index_exact(r, i)
                     : plugin_index_exact(plugin_mag_exact(r, i, two_over_n), p.gain_db, p.range_db);
@@ -165,7 +213,14 @@ __global__ __launch_bounds__(kThreads) void stft_general_kernel(StftParams p, Fa
           tile[fl * tile_stride + (y - p.bin_lo)] = (unsigned char)idx;
       } else {
         float v;
-        if constexpr (sizeof(A) == 8) {
+        if (fb) {
+          if (p.out_kind == SONO_OUT_F32_MAG) {
+            v = r;
+          } else {
+            const double sv = ((double)r > 1e-12) ? (double)r : 1e-12;
+            v = (float)(20 * log10(sv));
+          }
+        } else if constexpr (sizeof(A) == 8) {
           const double e = r, s = i;
           const double mag = sqrt(e * e + s * s);
           const float m = (p.scale_mode == SONO_SCALE_WORKER_LOG5) ? (float)mag : (float)(two_over_n * mag);
@@ -221,6 +276,10 @@ int launch_stft_general(const StftParams& p, bool exact_f64, void* stream_v) {
     lds += (size_t)ft * stride;
   } else {
     ft = 8;
+  }
+  if (p.fb_bin) {
+    if (p.scale_mode != SONO_SCALE_PLUGIN_DB || !p.fb_w0 || !p.fb_w1) return SONO_ERR_ARG;
+    lds = (size_t)p.n * 2 * sizeof(float) + (size_t)ft * stride + (size_t)(p.n / 2) * sizeof(float);
   }
   const uint64_t blocks = (p.nframes + ft - 1) / ft;
   if (blocks > 0x7fffffffull) return SONO_ERR_ARG;

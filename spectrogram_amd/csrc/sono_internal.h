@@ -37,6 +37,9 @@ struct StftParams {
   const void* fast_table; // device: per-size twiddle matrix of the fast kernels, or nullptr
   uint32_t fast_mode;     // 0: no fast kernel; 1: exact roots of unity (fast_table); 2: the per-stage table `twiddles`
   uint32_t mw_ok;         // the twiddle table starts every stage with (1, 0): the 2048/4096-point kernel may run
+  const int32_t* fb_bin;  // device: non-linear frequency scale, first tap of output bin i (n/2 entries), or nullptr = linear
+  const double* fb_w0;    // device: weight of bin fb_bin[i]
+  const double* fb_w1;    // device: weight of bin fb_bin[i] + 1
   void* tile_scratch;     // device: fast_rgba_scratch_bytes() of scratch for the fused RGBA output, or nullptr
   uint32_t scale_mode, out_kind, in_kind;
   double gain_db, range_db;

@@ -82,6 +82,17 @@ class Engine:
             raise ValueError("twiddle tables must have fft_n-1 entries each")
         self._check(self._lib.sono_set_tables(self._ctx, F.ptr(w), F.ptr(c), F.ptr(s)))
 
+    def set_filterbank(self, bin=None, w0=None, w1=None):
+        """Two-tap filter bank of a non-linear frequency scale (fft_n/2 filters); None removes it."""
+        if bin is None:
+            self._check(self._lib.sono_set_filterbank(self._ctx, None, None, None))
+            return
+        b = np.ascontiguousarray(bin, np.int32)
+        a0, a1 = np.ascontiguousarray(w0, np.float64), np.ascontiguousarray(w1, np.float64)
+        if not (b.shape[0] == a0.shape[0] == a1.shape[0] == self.cfg.fft_n // 2):
+            raise ValueError("a filter bank has fft_n/2 filters")
+        self._check(self._lib.sono_set_filterbank(self._ctx, F.ptr(b), F.ptr(a0), F.ptr(a1)))
+
     # -- geometry
     def geometry(self, n_samples):
         g = F.SonoGeometry()
@@ -225,6 +236,33 @@ def geometry_for(fft_n, hop, frame_rule, n_samples, bin_lo=0, bin_hi=0):
     if rc != F.OK:
         raise F.SonoError(rc, "bad geometry arguments")
     return g
+
+
+def filterbank_table(scale, fft_n, sample_rate, filters=None):
+    """createFilterBank (spectrogram.esm.js:389-411) as (first tap, weight of it, weight of the next bin)."""
+    filters = fft_n // 2 if filters is None else int(filters)
+    b, w0, w1 = np.empty(filters, np.int32), np.empty(filters, np.float64), np.empty(filters, np.float64)
+    rc = F.lib().sono_filterbank_table(F.FREQ_SCALES[scale], int(fft_n), float(sample_rate), filters, F.ptr(b), F.ptr(w0), F.ptr(w1))
+    if rc != F.OK:
+        raise F.SonoError(rc, "bad filter bank arguments")
+    return b, w0, w1
+
+
+def hz_to_scale(scale, hz):
+    return float(F.lib().sono_hz_to_scale(F.FREQ_SCALES[scale], float(hz)))
+
+
+def scale_to_hz(scale, v):
+    return float(F.lib().sono_scale_to_hz(F.FREQ_SCALES[scale], float(v)))
+
+
+def plugin_crop_scaled(bins, sample_rate, fmin_hz, fmax_hz, scale):
+    sy, sh = C.c_int64(0), C.c_int64(0)
+    rc = F.lib().sono_plugin_crop_scaled(int(bins), float(sample_rate), float(fmin_hz), float(fmax_hz), F.FREQ_SCALES[scale],
+                                         C.byref(sy), C.byref(sh))
+    if rc != F.OK:
+        raise F.SonoError(rc, "bad crop arguments")
+    return sy.value, sh.value
 
 
 def plugin_crop(bins, sample_rate, fmin_hz, fmax_hz):

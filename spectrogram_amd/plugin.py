@@ -77,8 +77,12 @@ class Spectrogram:
         self._engines = {}
 
     # -------------------------------------------------------------------------------------
-    def _engine(self, hop):
-        key = (self.fftSamples, hop, self.windowFunc, self.alpha, self.gainDB, self.rangeDB, self.arith, self.twiddles)
+    def _engine(self, hop, sample_rate=None):
+        if self.scale not in F.FREQ_SCALES:
+            raise ValueError("unknown scale '%s'" % self.scale)
+        fb_rate = sample_rate if self.scale != "linear" else None
+        key = (self.fftSamples, hop, self.windowFunc, self.alpha, self.gainDB, self.rangeDB, self.arith, self.twiddles,
+               self.scale, fb_rate)
         eng = self._engines.get(key)
         if eng is None:
             n = self.fftSamples
@@ -92,14 +96,13 @@ class Spectrogram:
                 arith=F.ARITH_EXACT_F64 if self.arith == "exact" else F.ARITH_FAST_F32,
                 out_kind=F.OUT_U8_INDEX, device=self.device)
             eng.set_colormap(self._colorMapUint)
+            if fb_rate is not None:      # :509-521: numMelFilters = ... = fftSamples / 2 filters over [0, sampleRate / 2]
+                eng.set_filterbank(*E.filterbank_table(self.scale, n, fb_rate))
             self._engines[key] = eng
         return eng
 
     def getFrequencies(self, buffer, canvas_width=None):
-        """spectrogram.esm.js:492-542 with scale 'linear'.  Returns list[channels] of uint8 [F][N/2]."""
-        if self.scale != "linear":
-            raise NotImplementedError("scale '%s': only 'linear' (what SonoRadar's wsManager passes) runs on the GPU"
-                                      % self.scale)
+        """spectrogram.esm.js:492-542.  Returns list[channels] of uint8 [F][N/2]."""
         self.frequencyMax = self.frequencyMax or buffer.sampleRate / 2          # :496
         self.buffer = buffer
         n = self.fftSamples
@@ -109,7 +112,7 @@ class Spectrogram:
         hop = n - noverlap
         if hop <= 0:
             raise ValueError("noverlap must be smaller than fftSamples")
-        eng = self._engine(hop)
+        eng = self._engine(hop, buffer.sampleRate)
         return [eng.stft(buffer.getChannelData(ch)) for ch in range(channels)]
 
     def resample(self, frames, width):
@@ -125,7 +128,7 @@ class Spectrogram:
     def crop_rows(self, bins):
         """Source-row window drawSpectrogram hands to createImageBitmap (:377-380): (sy, sh)."""
         sr = self.buffer.sampleRate
-        return E.plugin_crop(bins, sr, self.frequencyMin, self.frequencyMax)
+        return E.plugin_crop_scaled(bins, sr, self.frequencyMin, self.frequencyMax, self.scale)
 
     def drawSpectrogram(self, frames, width):
         """LUT + flip + crop of spectrogram.esm.js:345-388 for one channel.  Returns

@@ -351,6 +351,63 @@ renderCase('bat', { N: 4096, noverlap: 3840, W: 30, fmin: 15000, fmax: 120000, c
 renderCase('bat', { N: 1024, noverlap: 768, W: 41, fmin: 0, fmax: 250000, colorMapName: 'gray', tag: 'd' });   // fmax > Nyquist
 renderCase('tone', { N: 512, noverlap: 384, W: 50, fmin: 20000, fmax: 90000, colorMapName: 'igray', tag: 'e' });
 
+// ================================================================ 7b. non-linear frequency scales (filter banks)
+{
+  const SCALES = ['mel', 'logarithmic', 'bark', 'erb'];
+  const fbCases = [];
+  for (const scale of SCALES)
+    for (const [N, sr] of [[1024, 384000], [512, 44100], [2048, 500000]]) {
+      const p = makePlugin({ fftSamples: N, noverlap: N / 2, colorMap: 'gray', scale }, 10);
+      const fns = { mel: [p.hzToMel, p.melToHz], logarithmic: [p.hzToLog, p.logToHz], bark: [p.hzToBark, p.barkToHz], erb: [p.hzToErb, p.erbToHz] }[scale];
+      const bank = p.createFilterBank(N / 2, sr, fns[0], fns[1]);
+      // each row has at most two non-zero taps: store (first tap index, weight of the first, weight of the second)
+      const bin = new Int32Array(N / 2), w0 = new Float64Array(N / 2), w1 = new Float64Array(N / 2);
+      for (let e = 0; e < N / 2; e++) {
+        const row = bank[e];
+        let o = -1;
+        for (let k = 0; k < row.length; k++) if (row[k] !== 0 && row[k] !== undefined) { o = k; break; }
+        // rows whose first weight is exactly 0 (c == 1) cannot be told from their second tap alone: recompute o as the reference does
+        const h = sr / N, hz = fns[1](fns[0](0) + e / (N / 2) * (fns[0](sr / 2) - fns[0](0)));
+        o = Math.floor(hz / h);
+        bin[e] = o; w0[e] = row[o] === undefined ? 0 : row[o]; w1[e] = row[o + 1] === undefined ? 0 : row[o + 1];
+      }
+      const id = `fb_${scale}_${N}_${sr}`;
+      fbCases.push({ scale, N, sr, bin: writeBin(id + '_bin.i32', bin), w0: writeBin(id + '_w0.f64', w0), w1: writeBin(id + '_w1.f64', w1) });
+    }
+  manifest.cases.push({ kind: 'plugin_filterbanks', banks: fbCases });
+  const pts = [0, 1, 20, 440, 1000, 1960, 7000, 22050, 96000, 192000, 250000];
+  const p0 = makePlugin({ fftSamples: 512, colorMap: 'gray', scale: 'mel' }, 10);
+  const conv = {};
+  for (const scale of SCALES) {
+    p0.scale = scale;
+    conv[scale] = pts.map((hz) => ({ hz, to: p0.hzToScale(hz), back: p0.scaleToHz(p0.hzToScale(hz)) }));
+  }
+  manifest.cases.push({ kind: 'plugin_scale_conversions', conv });
+  let sid = 0;
+  for (const scale of SCALES)
+    for (const [sig, N, nov] of [['bat', 1024, 768], ['tone', 512, 256], ['nan_probe', 1024, 768]]) {
+      const { x, sr } = signals[sig];
+      const p = makePlugin({ fftSamples: N, noverlap: nov, colorMap: 'gray', scale }, 300);
+      const frames = p.getFrequencies(audioBuffer(x, sr))[0];
+      const id = `sc${String(sid++).padStart(2, '0')}`;
+      manifest.cases.push({ kind: 'plugin_scale_frequencies', id, scale, signal: sig, N, noverlap: nov, frames: frames.length, bins: N / 2,
+                            data: writeBin(`${id}.u8`, flattenFrames(frames)) });
+    }
+  // crop window of drawSpectrogram under each scale
+  const rows = [];
+  for (const scale of SCALES)
+    for (const [N, sr, fmin, fmax] of [[1024, 384000, 10000, 128000], [1024, 384000, 15000, 120000], [512, 44100, 100, 8000], [2048, 500000, 0, 0], [1024, 96000, 1000, 60000]]) {
+      const x = new Float32Array(N + 16);
+      const p = makePlugin({ fftSamples: N, noverlap: N - 8, colorMap: 'gray', scale, frequencyMin: fmin, frequencyMax: fmax }, 2);
+      p.wavesurfer.getDecodedData = () => audioBuffer(x, sr);
+      P.captured.bitmaps.length = 0;
+      p.render();
+      const b = P.captured.bitmaps[0];
+      rows.push({ scale, N, sr, fmin, fmax, sy: b.sy, sh: b.sh });
+    }
+  manifest.cases.push({ kind: 'plugin_scale_crop_grid', rows });
+}
+
 // crop-window grid (pure integer rule of drawSpectrogram for scale 'linear')
 {
   const rows = [];

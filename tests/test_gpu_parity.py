@@ -516,3 +516,24 @@ def test_full_size_worker_render_rgba_properties():
     for dlt in (-1, 0, 1):
         ok |= np.all(head == l4[np.clip(refi[:, period_frames:2 * period_frames] + dlt, 0, 255)], axis=-1)
     assert ok.all()
+
+
+# ------------------------------------------------------------------ non-linear frequency scales (plugin option `scale`)
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", G.cases("plugin_scale_frequencies"), ids=lambda c: c["id"])
+def test_plugin_scaled_get_frequencies(case):
+    """mel / logarithmic / bark / erb: filter bank between magnitudes and quantiser (spectrogram.esm.js:479-530).
+    Exact arithmetic reproduces the reference's bytes up to the last-bit differences of log10/pow between
+    this libm and V8 in the filter weights (at most one index step, vanishingly rare); float32 within 1 LSB."""
+    from spectrogram_amd.plugin import AudioBuffer, Spectrogram
+    x = G.signal(case["signal"])
+    sr = G.sample_rate(case["signal"])
+    ref = G.load(case["data"], np.uint8).reshape(case["frames"], case["bins"])
+    for arith, frac in (("exact", 1e-4), ("fast", 0.02)):
+        p = Spectrogram.create({"fftSamples": case["N"], "noverlap": case["noverlap"], "colorMap": "gray", "scale": case["scale"],
+                                "arith": arith})
+        got = p.getFrequencies(AudioBuffer([x], sr))[0]
+        p.destroy()
+        d = cyc_diff(got, ref)
+        assert got.shape == ref.shape and d.max() <= 1 and (d != 0).mean() <= frac, (arith, d.max(), (d != 0).mean())
+    assert np.array_equal(oracle.plugin_get_frequencies_scaled(x, case["N"], case["noverlap"], case["scale"], sr).shape, ref.shape)

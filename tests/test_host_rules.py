@@ -164,3 +164,23 @@ def test_create_without_gpu_reports_cleanly():
         E.Engine(hop=0)
     with pytest.raises(F.SonoError):
         E.Engine(window_id=77)
+
+
+# ------------------------------------------------------------------ non-linear frequency scales
+def test_scale_rules_match_reference():
+    (conv,) = G.cases("plugin_scale_conversions")
+    for scale, rows in conv["conv"].items():
+        for row in rows:
+            assert abs(E.hz_to_scale(scale, row["hz"]) - row["to"]) <= 4e-16 * abs(row["to"]) + 1e-300
+            assert abs(E.scale_to_hz(scale, row["to"]) - row["back"]) <= 2e-13 * abs(row["back"]) + 1e-12
+    assert E.hz_to_scale("linear", 1234.5) == 1234.5
+    (banks,) = G.cases("plugin_filterbanks")
+    for b in banks["banks"]:
+        bin_, w0, w1 = E.filterbank_table(b["scale"], b["N"], b["sr"])
+        rb, r0, r1 = G.load(b["bin"], np.int32), G.load(b["w0"], np.float64), G.load(b["w1"], np.float64)
+        assert np.array_equal(bin_, rb)
+        assert np.abs(w0 - r0)[rb <= b["N"] // 2].max() <= 1e-9 and np.abs(w1 - r1)[rb + 1 <= b["N"] // 2].max() <= 1e-9
+    (grid,) = G.cases("plugin_scale_crop_grid")
+    for r in grid["rows"]:
+        assert E.plugin_crop_scaled(r["N"] // 2, r["sr"], r["fmin"], r["fmax"], r["scale"]) == (r["sy"], r["sh"]), r
+    assert E.plugin_crop_scaled(512, 384000, 10000, 128000, "linear") == E.plugin_crop(512, 384000, 10000, 128000)

@@ -248,3 +248,42 @@ def test_js_worker_restatement_bench_mode(tmp_path):
     assert d["workers"] == 2 and d["chunks"] >= 2 and d["msamples_per_s"] > 0
     hop = 256
     assert d["samples"] == (len(x) - 1024) // hop * hop + hop or d["samples"] <= len(x)
+
+
+# ------------------------------------------------------------------ non-linear frequency scales (filter banks)
+SCALES = ("mel", "logarithmic", "bark", "erb")
+
+
+def test_scale_conversions_and_filterbanks():
+    (conv,) = G.cases("plugin_scale_conversions")
+    for scale in SCALES:
+        for row in conv["conv"][scale]:
+            to = oracle.hz_to_scale(scale, row["hz"])
+            assert abs(to - row["to"]) <= 4e-16 * abs(row["to"]) + 1e-300            # libm vs V8: at most an ulp or two
+            assert abs(oracle.scale_to_hz(scale, row["to"]) - row["back"]) <= 2e-13 * abs(row["back"]) + 1e-12
+    (banks,) = G.cases("plugin_filterbanks")
+    for b in banks["banks"]:
+        bin_, w0, w1 = oracle.plugin_filterbank(b["scale"], b["N"], b["sr"])
+        rb, r0, r1 = G.load(b["bin"], np.int32), G.load(b["w0"], np.float64), G.load(b["w1"], np.float64)
+        assert np.array_equal(bin_, rb), (b["scale"], b["N"])
+        inside = rb + 1 <= b["N"] // 2                      # the reference's rows are N/2 + 1 long: taps past that are not stored
+        assert np.abs(w0 - r0)[rb <= b["N"] // 2].max() <= 1e-9 and np.abs(w1 - r1)[inside].max() <= 1e-9
+
+
+@pytest.mark.parametrize("case", G.cases("plugin_scale_frequencies"), ids=lambda c: c["id"])
+def test_plugin_get_frequencies_scaled(case):
+    x = G.signal(case["signal"])
+    got = oracle.plugin_get_frequencies_scaled(x, case["N"], case["noverlap"], case["scale"], G.sample_rate(case["signal"]))
+    ref = G.load(case["data"], np.uint8).reshape(case["frames"], case["bins"])
+    assert got.shape == ref.shape
+    # the filter weights go through log10/pow, where glibc and V8 may differ in the last bit of a double;
+    # after the float32 accumulation and the quantiser that could move an index by one at most
+    d = np.abs(got.astype(int) - ref.astype(int))
+    d = np.minimum(d, 256 - d)
+    assert d.max() <= 1 and (d != 0).mean() <= 1e-4
+
+
+def test_scaled_crop_grid():
+    (grid,) = G.cases("plugin_scale_crop_grid")
+    for r in grid["rows"]:
+        assert oracle.plugin_crop_scaled(r["N"] // 2, r["sr"], r["fmin"], r["fmax"], r["scale"]) == (r["sy"], r["sh"]), r
