@@ -191,6 +191,23 @@ def main():
             "checksum": checksum,
         }
 
+    if rank == 0 and world == 1:
+        # what this box's memory system delivers to the simplest possible kernels, next to the nominal 8 TB/s:
+        # a device-to-device copy (reads + writes) and a fill (writes only) of the recording-sized buffer
+        y = torch.empty_like(x)
+        for fn, key, nbytes in ((lambda: y.copy_(x), "measured_copy_gbps", 2 * x.numel() * 4),
+                                (lambda: y.fill_(1.0), "measured_fill_gbps", x.numel() * 4)):
+            fn()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(5):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            result["roofline"][key] = round(nbytes * 5 / (e0.elapsed_time(e1) * 1e-3) / 1e9, 1)
+        del y
+
     if rank == 0 and world == 1 and not args.no_variants:
         # other entry points of the same path on the same recording (not the headline; same timing method)
         k = max(3, args.steps // 4)
