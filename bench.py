@@ -81,6 +81,8 @@ def main():
     ap.add_argument("--seconds", type=int, default=3600, help="recording length per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-variants", action="store_true")
+    ap.add_argument("--rehearse", action="store_true",
+                    help="multi-rank dry run on a box with one GPU: every rank uses cuda:0 and the ranks meet over gloo")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -97,13 +99,19 @@ def main():
     from spectrogram_amd import _ffi as F
     from spectrogram_amd import engine as E
 
+    if args.rehearse:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     def barrier():
+        torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -153,7 +161,7 @@ def main():
 
     wall, kern_ms, out_bytes, geo, checksum = run(args.out, args.steps, args.warmup)
     if world > 1:
-        t = torch.tensor([wall], dtype=torch.float64, device=dev)
+        t = torch.tensor([wall], dtype=torch.float64, device="cpu" if args.rehearse else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall = float(t.item())
     value = world * L * args.steps / wall / 1e6
