@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Headline benchmark: STFT Msamples/s at FFT 1024, Hann, 75 % overlap (hop 256) on MI355X.
 
-Workload (BASELINE.json configs[1]): one hour of synthetic 384 kHz mono bat-call PCM per GPU,
+Workload: one hour of synthetic 384 kHz mono bat-call PCM per GPU,
 resident in HBM before the timed region; one step = one pass of the worker-path transform
 (spectrogramWorker.js semantics: worker Hann, accurate twiddles, log10|X|/5 quantiser, colour LUT,
 RGBA ImageData layout) over the whole recording.  `--out u8` stops at the colour indices

@@ -296,7 +296,7 @@ def test_errors_through_the_abi():
 
 
 def test_full_size_periodic_property():
-    """BASELINE size (1 h x 384 kHz, FFT 1024, hop 256) on device memory: a signal with period
+    """Benchmark size (1 h x 384 kHz, FFT 1024, hop 256) on device memory: a signal with period
     64*hop must give columns that repeat every 64 frames, and the first columns must equal the
     CPU checker's.  Size-independent property; nothing is copied back except a checksum."""
     torch = pytest.importorskip("torch")

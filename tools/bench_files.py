@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Per-file batch benchmark (BASELINE.json configs[2] on one GPU): many 5 s x 500 kHz int16 recordings
+"""Per-file batch benchmark on one GPU: many 5 s x 500 kHz int16 recordings
 from host memory to host memory, worker render (RGBA) or colour indices (u8), through the overlapped
 FilePipeline and, for comparison, through synchronous sono_stft calls on one context.  PCIe-inclusive.
 

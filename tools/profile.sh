@@ -6,7 +6,7 @@
 # summary.json and traffic.json.
 # Usage (repo root, on the box): bash tools/profile.sh <tag> [seconds=3600]
 set -u
-TAG=${1:-r01}
+TAG=${1:-profile}
 SEC=${2:-3600}
 OUT=gpurun_out/prof_$TAG
 W=/tmp/prof_$TAG
