@@ -695,6 +695,52 @@ static napi_value js_plugin_crop_scaled(napi_env env, napi_callback_info info) {
   return o;
 }
 
+/* ---- overlapped per-file batches: page-locked host buffers + host-async transform ------------- */
+
+static void pinned_finalize(napi_env env, void* data, void* hint) {
+  (void)env;
+  (void)hint;
+  sono_host_free(data);
+}
+
+/* hostAlloc(bytes) -> ArrayBuffer over page-locked memory (freed when the buffer is collected) */
+static napi_value js_host_alloc(napi_env env, napi_callback_info info) {
+  ARGS(env, info, 1);
+  uint64_t bytes;
+  if (!get_u64(env, argv[0], &bytes) || !bytes) return throw_msg(env, "hostAlloc(bytes)");
+  void* p = sono_host_malloc(bytes);
+  if (!p) return throw_msg(env, "page-locked allocation failed");
+  napi_value ab;
+  if (napi_create_external_arraybuffer(env, p, (size_t)bytes, pinned_finalize, NULL, &ab) != napi_ok) {
+    sono_host_free(p);
+    return throw_msg(env, "external ArrayBuffer failed");
+  }
+  return ab;
+}
+
+/* stftHostAsync(handle, inTypedArray, samples, outUint8Array): enqueues copy-in, transform, copy-out; wait(handle) completes it.
+ * Both arrays must stay alive and untouched until then (use hostAlloc memory for the copies to overlap). */
+static napi_value js_stft_host_async(napi_env env, napi_callback_info info) {
+  ARGS(env, info, 4);
+  handle_t* h = get_handle(env, argv[0]);
+  if (!h) return NULL;
+  napi_typedarray_type ti, to;
+  void *in, *out;
+  uint64_t L;
+  int64_t nin = ta_data(env, argv[1], &ti, &in), nout = ta_data(env, argv[3], &to, &out);
+  if (nin < 0 || nout < 0 || !get_u64(env, argv[2], &L) || (to != napi_uint8_array && to != napi_uint8_clamped_array))
+    return throw_msg(env, "stftHostAsync(handle, input, samples, Uint8Array output)");
+  sono_config cfg;
+  sono_get_config(h->ctx, &cfg);
+  const napi_typedarray_type want = cfg.in_kind == SONO_IN_I16 ? napi_int16_array : napi_float32_array;
+  if (ti != want || (uint64_t)nin < L) return throw_msg(env, "stftHostAsync: input type or length does not match the context");
+  const uint64_t need = sono_out_bytes(h->ctx, L);
+  if ((uint64_t)nout < need) return throw_msg(env, "stftHostAsync: output too small");
+  int rc = sono_stft_host_async(h->ctx, in, L, out, (uint64_t)nout);
+  if (rc != SONO_OK) return throw_ctx(env, h, rc);
+  return make_num(env, (double)need);
+}
+
 #define EXPORT(name, fn)                                                     \
   do {                                                                       \
     napi_value f_;                                                           \
@@ -730,6 +776,8 @@ static napi_value init(napi_env env, napi_value exports) {
   EXPORT("workerLut", js_worker_lut);
   EXPORT("windowTable", js_window_table);
   EXPORT("geometryFor", js_geometry_for);
+  EXPORT("hostAlloc", js_host_alloc);
+  EXPORT("stftHostAsync", js_stft_host_async);
   EXPORT("setFilterbank", js_set_filterbank);
   EXPORT("pluginCropScaled", js_plugin_crop_scaled);
   EXPORT("wavParse", js_wav_parse);

@@ -46,3 +46,12 @@ def test_worker_threads_contract_on_gpu():
     p, res = run_node("test_worker_threads.js")
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
     assert res == {"rendered": True, "width": 41, "height": 512, "identical": True, "input_detached": True}
+
+
+@needs_node
+@pytest.mark.gpu
+def test_node_file_batch_on_gpu():
+    """node/batch.js: .wav files from disk through the overlapped per-file pipeline equal synchronous transforms."""
+    p, res = run_node("test_batch.js")
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    assert res["failures"] == 0 and res["checks"] >= 40
