@@ -189,6 +189,14 @@ int sono_filterbank_table(uint32_t scale, uint32_t fft_n, double sample_rate, ui
 /* drawSpectrogram's source-row window under a scale, :377-380 (scale 0 == sono_plugin_crop). */
 int sono_plugin_crop_scaled(uint32_t bins, double sample_rate, double fmin_hz, double fmax_hz, uint32_t scale, int64_t* sy,
                             int64_t* sh);
+/* Where drawSpectrogram puts the cropped rows on its canvas (:377-381, one channel): they cover canvas rows
+ * [dy, dy + dh) of `height`; fill_background = 1 when the canvas is first filled with the background colour
+ * (frequencyMax above Nyquist, :357-361). */
+int sono_plugin_draw_rect(double sample_rate, double fmin_hz, double fmax_hz, uint32_t scale, uint32_t height, double* dy,
+                          double* dh, int* fill_background);
+/* That background colour: the last colour-map entry's four numbers written into a CSS "rgba(r, g, b, a)" string as
+ * they are (:358-360), so r/g/b in 0..1 read as channel values 0..255. */
+int sono_plugin_background(const double* colormap_last_rgba, uint8_t* rgba);
 /* Colour LUTs: 256 RGBA doubles -> 1024 bytes.  Plugin rule spectrogram.esm.js:262-271, worker
  * rule spectrogramWorker.js:128-143 (NaN channel = absent). */
 int sono_plugin_lut(const double* colormap_rgba, uint8_t* lut_rgba);
@@ -267,6 +275,15 @@ int sono_resample(sono_ctx* ctx, const uint8_t* in, uint64_t in_frames, uint32_t
  * [width][bins] uint8 -> rows [row0, row0+rows) of the [bins][width] RGBA image. */
 int sono_colorize(sono_ctx* ctx, const uint8_t* frames, uint64_t width, uint32_t bins, uint32_t row0,
                   uint32_t rows, uint8_t* rgba, int mem);
+
+/* The canvas step of drawSpectrogram (spectrogram.esm.js:357-361,377-381): LUT + flip of [width][bins] uint8
+ * columns, rows [sy, sy + sh) of that image stretched over canvas rows [dy, dy + dh) of a [height][width] RGBA
+ * canvas; the rest is `background_rgba` (4 bytes; NULL = transparent black, a cleared canvas).  The browser's
+ * drawImage filter is implementation-defined, so this step has no pinned counterpart: the filter here is
+ * bilinear along y with clamped edges, sampled at pixel centres, float32 with round-half-up; with dh == sh and
+ * an integer dy it copies the rows. */
+int sono_canvas_draw(sono_ctx* ctx, const uint8_t* frames, uint64_t width, uint32_t bins, int64_t sy, int64_t sh, double dy,
+                     double dh, uint32_t height, const uint8_t* background_rgba, uint8_t* canvas, int mem);
 
 /* Per-frame peak over the kept band of a [frames][bins] uint8 index matrix: first bin holding
  * the maximum (the strict-> rule of spectrogram.esm.js:196) and that maximum. */

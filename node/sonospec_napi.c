@@ -23,10 +23,10 @@
 
 /* argv holds up to 8 values; argc is clamped to that (napi_get_cb_info reports the real count) */
 #define ARGS(env, info, n)                                                  \
-  size_t argc = 8;                                                          \
-  napi_value argv[8];                                                       \
+  size_t argc = 12;                                                         \
+  napi_value argv[12];                                                      \
   NAPI_OK(env, napi_get_cb_info((env), (info), &argc, argv, NULL, NULL));   \
-  if (argc > 8) argc = 8;                                                   \
+  if (argc > 12) argc = 12;                                                 \
   if (argc < (n)) {                                                         \
     napi_throw_type_error((env), NULL, "too few arguments");                \
     return NULL;                                                            \
@@ -695,6 +695,72 @@ static napi_value js_plugin_crop_scaled(napi_env env, napi_callback_info info) {
   return o;
 }
 
+/* pluginDrawRect(sampleRate, fmin, fmax, scale, height) -> {dy, dh, fill} */
+static napi_value js_plugin_draw_rect(napi_env env, napi_callback_info info) {
+  ARGS(env, info, 5);
+  uint32_t scale, height;
+  double sr, f0, f1;
+  if (!get_f64(env, argv[0], &sr) || !get_f64(env, argv[1], &f0) || !get_f64(env, argv[2], &f1) || !get_u32(env, argv[3], &scale) ||
+      !get_u32(env, argv[4], &height))
+    return throw_msg(env, "pluginDrawRect(sampleRate, fmin, fmax, scale, height)");
+  double dy = 0, dh = 0;
+  int fill = 0;
+  if (sono_plugin_draw_rect(sr, f0, f1, scale, height, &dy, &dh, &fill) != SONO_OK) return throw_msg(env, "pluginDrawRect: bad arguments");
+  napi_value o, b;
+  napi_create_object(env, &o);
+  napi_set_named_property(env, o, "dy", make_num(env, dy));
+  napi_set_named_property(env, o, "dh", make_num(env, dh));
+  napi_get_boolean(env, fill != 0, &b);
+  napi_set_named_property(env, o, "fill", b);
+  return o;
+}
+
+/* pluginBackground(Float64Array(4)) -> Uint8Array(4) */
+static napi_value js_plugin_background(napi_env env, napi_callback_info info) {
+  ARGS(env, info, 1);
+  napi_typedarray_type t;
+  void* in;
+  int64_t n = ta_data(env, argv[0], &t, &in);
+  if (n < 4 || t != napi_float64_array) return throw_msg(env, "pluginBackground(Float64Array(4))");
+  void* out;
+  napi_value result = new_typed(env, napi_uint8_array, 4, 1, &out);
+  if (!result) return NULL;
+  if (sono_plugin_background((const double*)in, (uint8_t*)out) != SONO_OK) return throw_msg(env, "pluginBackground: bad arguments");
+  return result;
+}
+
+/* canvasDraw(handle, Uint8Array columns, width, bins, sy, sh, dy, dh, height, background Uint8Array(4) | null)
+ * -> Uint8ClampedArray(height * width * 4) */
+static napi_value js_canvas_draw(napi_env env, napi_callback_info info) {
+  ARGS(env, info, 10);
+  handle_t* h = get_handle(env, argv[0]);
+  if (!h) return NULL;
+  napi_typedarray_type t;
+  void* in;
+  int64_t n = ta_data(env, argv[1], &t, &in);
+  uint64_t W;
+  uint32_t B, height;
+  double sy, sh, dy, dh;
+  if (n < 0 || !get_u64(env, argv[2], &W) || !get_u32(env, argv[3], &B) || !get_f64(env, argv[4], &sy) || !get_f64(env, argv[5], &sh) ||
+      !get_f64(env, argv[6], &dy) || !get_f64(env, argv[7], &dh) || !get_u32(env, argv[8], &height) || (uint64_t)n < W * B)
+    return throw_msg(env, "canvasDraw(handle, Uint8Array, width, bins, sy, sh, dy, dh, height, background)");
+  const uint8_t* bg = NULL;
+  napi_valuetype vt;
+  napi_typeof(env, argv[9], &vt);
+  if (vt != napi_null && vt != napi_undefined) {
+    void* bgp;
+    int64_t bn = ta_data(env, argv[9], &t, &bgp);
+    if (bn < 4) return throw_msg(env, "canvasDraw: background must hold 4 bytes");
+    bg = (const uint8_t*)bgp;
+  }
+  void* out;
+  napi_value result = new_typed(env, napi_uint8_clamped_array, (size_t)(W * height * 4), 1, &out);
+  if (!result) return NULL;
+  if (W * height == 0) return result;
+  int rc = sono_canvas_draw(h->ctx, (const uint8_t*)in, W, B, (int64_t)sy, (int64_t)sh, dy, dh, height, bg, (uint8_t*)out, SONO_MEM_HOST);
+  return rc == SONO_OK ? result : throw_ctx(env, h, rc);
+}
+
 /* ---- overlapped per-file batches: page-locked host buffers + host-async transform ------------- */
 
 static void pinned_finalize(napi_env env, void* data, void* hint) {
@@ -780,6 +846,9 @@ static napi_value init(napi_env env, napi_value exports) {
   EXPORT("stftHostAsync", js_stft_host_async);
   EXPORT("setFilterbank", js_set_filterbank);
   EXPORT("pluginCropScaled", js_plugin_crop_scaled);
+  EXPORT("pluginDrawRect", js_plugin_draw_rect);
+  EXPORT("pluginBackground", js_plugin_background);
+  EXPORT("canvasDraw", js_canvas_draw);
   EXPORT("wavParse", js_wav_parse);
   EXPORT("wavGuano", js_wav_guano);
   EXPORT("guanoFields", js_guano_fields);

@@ -176,6 +176,27 @@ class Spectrogram {
     return this.drawSpectrogram(frames, width);
   }
 
+  // The whole of drawSpectrogram (:345-388) for one channel, down to the canvas pixels: ImageData-shaped
+  // { width, height, data }.  The browser's drawImage filter is implementation-defined; the engine's is
+  // bilinear along y between pixel centres.
+  drawCanvas(frames, width) {
+    const cols = this.resample(frames, width);
+    const B = cols.length ? cols[0].length : this.fftSamples / 2;
+    const h = this._anyEngine();
+    N.setColormap(h, this._colorMapUint);
+    const sr = this.buffer.sampleRate, scale = SCALE_IDS[this.scale];
+    const crop = N.pluginCropScaled(B, sr, this.frequencyMin, this.frequencyMax, scale);                 // :377-380
+    const rect = N.pluginDrawRect(sr, this.frequencyMin, this.frequencyMax, scale, this.height);         // :381
+    const last = this.colorMap[this.colorMap.length - 1];
+    const bg = rect.fill ? N.pluginBackground(Float64Array.from(last)) : null;                           // :357-361
+    const data = N.canvasDraw(h, cols.flat || new Uint8Array(0), width, B, crop.sy, crop.sh, rect.dy, rect.dh, this.height, bg);
+    return { width, height: this.height, data };
+  }
+
+  renderCanvas(buffer, width) {
+    return this.drawCanvas(this.getFrequencies(buffer)[0], width);
+  }
+
   destroy() {
     for (const h of this._engines.values()) N.destroy(h);
     this._engines.clear();

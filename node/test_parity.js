@@ -166,6 +166,37 @@ if (!cpuOnly) {
     ok(img.crop.sy === c.crop.sy && img.crop.sh === c.crop.sh, 'plugin crop ' + c.id);
     p.destroy();
   }
+  // the canvas step: the reference's image (fixture) stretched by the engine's filter, restated here in JS
+  const stretch = (img, W, rows, sy, sh, dy, dh, height) => {
+    const out = new Uint8Array(height * W * 4), f = Math.fround;
+    for (let y = 0; y < height; y++) {
+      const yc = y + 0.5;
+      if (!(sh > 0 && dh > 0 && yc >= dy && yc < dy + dh)) continue;
+      let v = (yc - dy) * (sh / dh) - 0.5;
+      v = Math.min(Math.max(v, 0), sh - 1);
+      const i0 = Math.floor(v), i1 = Math.min(i0 + 1, sh - 1), t = f(v - i0), ra = sy + i0, rb = sy + i1;
+      for (let x = 0; x < W; x++)
+        for (let ch = 0; ch < 4; ch++) {
+          const a = ra >= 0 && ra < rows ? img[(ra * W + x) * 4 + ch] : 0, b = rb >= 0 && rb < rows ? img[(rb * W + x) * 4 + ch] : 0;
+          out[(y * W + x) * 4 + ch] = Math.floor(f(f(a + f(f(b - a) * t)) + 0.5));
+        }
+    }
+    return out;
+  };
+  for (const c of cases('plugin_render')) {
+    if (c.fmax > manifest.signals[c.signal].sample_rate / 2) continue;     // no background fill in these cases
+    const cm = (c.colormap === 'default' || c.colormap === 'rainbow') ? colormap(c.colormap) : c.colormap;
+    for (const height of [200, 800]) {
+      const p = Spectrogram.create({ fftSamples: c.N, noverlap: c.noverlap, colorMap: cm, scale: 'linear', frequencyMin: c.fmin,
+                                     frequencyMax: c.fmax, windowFunc: c.window, arith: 'exact', canvasWidth: c.out_width, height });
+      const sr = manifest.signals[c.signal].sample_rate;
+      const cv = p.renderCanvas(audioBuffer(signal(c.signal), sr), c.out_width);
+      const rect = S.native.pluginDrawRect(sr, c.fmin, c.fmax, 0, height);
+      const want = stretch(load(c.rgba, Uint8Array), c.image_width, c.image_height, c.crop.sy, c.crop.sh, rect.dy, rect.dh, height);
+      ok(cv.width === c.out_width && cv.height === height && equal(cv.data, want), 'plugin canvas ' + c.id + ' h' + height);
+      p.destroy();
+    }
+  }
   // non-linear frequency scales: exact arithmetic with this V8's filter weights reproduces the reference's bytes
   for (const c of cases('plugin_scale_frequencies')) {
     const sr = manifest.signals[c.signal].sample_rate;

@@ -190,6 +190,31 @@ def plugin_crop_scaled(bins, sample_rate, fmin, fmax, scale):
     return sy.value, sh.value
 
 
+def plugin_draw_rect(sample_rate, fmin, fmax, scale, height):
+    dy, dh, fill = C.c_double(0), C.c_double(0), C.c_int(0)
+    lib().orc_plugin_draw_rect(C.c_double(sample_rate), C.c_double(fmin), C.c_double(fmax), SCALE_IDS[scale], int(height),
+                               C.byref(dy), C.byref(dh), C.byref(fill))
+    return dy.value, dh.value, bool(fill.value)
+
+
+def plugin_background(last):
+    last = np.ascontiguousarray(last, np.float64).reshape(4)
+    out = np.empty(4, np.uint8)
+    lib().orc_plugin_background(_p(last, C.c_double), _p(out, C.c_uint8))
+    return out
+
+
+def canvas_draw(image, sy, sh, dy, dh, height, background=None):
+    """The engine's own drawImage filter on a rows x width x 4 image (parity unpinned: browser-defined step)."""
+    image = np.ascontiguousarray(image, np.uint8)
+    rows, width = image.shape[0], image.shape[1]
+    out = np.empty((int(height), width, 4), np.uint8)
+    bg = None if background is None else np.ascontiguousarray(background, np.uint8).reshape(4)
+    lib().orc_canvas_draw(_p(image, C.c_uint8), C.c_size_t(width), int(rows), C.c_long(int(sy)), C.c_long(int(sh)),
+                          C.c_double(dy), C.c_double(dh), int(height), _p(bg, C.c_uint8), _p(out, C.c_uint8))
+    return out
+
+
 def plugin_resample(frames, out_width):
     frames = np.ascontiguousarray(frames, np.uint8)
     F, B = frames.shape

@@ -370,6 +370,87 @@ void orc_plugin_draw(const uint8_t *frames, size_t width, int bins, const uint8_
     }
 }
 
+/* :377-381, channel h = 0: the cropped rows cover canvas rows [dy, dy + dh); :357 decides the fill. */
+void orc_plugin_draw_rect(double sample_rate, double fmin, double fmax, int scale, int height, double *dy, double *dh,
+                          int *fill_background) {
+  (void)fmin;
+  const double nyq = sample_rate / 2;
+  if (fmax == 0) fmax = nyq;
+  const double f = orc_hz_to_scale(scale, fmax) / orc_hz_to_scale(scale, nyq);
+  const double p = f < 1 ? f : 1;
+  *dy = height * (1 - p / f);
+  *dh = height * p / f;
+  *fill_background = fmax > nyq;
+}
+
+/* :358-360: the numbers of the last colour-map entry inside "rgba(r, g, b, a)"; CSS clamps r/g/b to 0..255
+ * and rounds them, clamps a to 0..1.  A NaN makes the string unparsable: fillStyle stays opaque black. */
+void orc_plugin_background(const double *last, uint8_t *rgba) {
+  if (isnan(last[0]) || isnan(last[1]) || isnan(last[2]) || isnan(last[3])) {
+    rgba[0] = rgba[1] = rgba[2] = 0;
+    rgba[3] = 255;
+    return;
+  }
+  for (int ch = 0; ch < 3; ch++) rgba[ch] = (uint8_t)js_round(fmin(fmax(last[ch], 0), 255));
+  rgba[3] = (uint8_t)js_round(fmin(fmax(last[3], 0), 1) * 255);
+}
+
+/* drawImage(bitmap, 0, dy, width, dh) of :380-381 on a height-row canvas, with the engine's own filter (the
+ * browser's is implementation-defined, so nothing in the reference pins this function): bilinear along y between
+ * pixel centres with clamped edges, float32 per channel, round half up; a canvas row is covered when its centre
+ * lies in [dy, dy + dh).  image: `rows` x width RGBA (orc_plugin_draw's output); crop rows [sy, sy + sh); rows
+ * outside the image are transparent black.  Pixels with alpha < 255 go source-over onto the background. */
+void orc_canvas_draw(const uint8_t *image, size_t width, int rows, long sy, long sh, double dy, double dh, int height,
+                     const uint8_t *background, uint8_t *canvas) {
+  static const uint8_t clear[4] = {0, 0, 0, 0};
+  const uint8_t *bg = background ? background : clear;
+  const int have_bg = bg[0] || bg[1] || bg[2] || bg[3];
+  for (int y = 0; y < height; y++) {
+    uint8_t *dst = canvas + (size_t)y * width * 4;
+    const double yc = y + 0.5;
+    const int covered = sh > 0 && dh > 0 && yc >= dy && yc < dy + dh;
+    long i0 = 0, i1 = 0;
+    float t = 0;
+    if (covered) {
+      double v = (yc - dy) * ((double)sh / dh) - 0.5;
+      if (v < 0) v = 0;
+      if (v > (double)(sh - 1)) v = (double)(sh - 1);
+      i0 = (long)floor(v);
+      i1 = i0 + 1 < sh ? i0 + 1 : sh - 1;
+      t = (float)(v - floor(v));
+    }
+    for (size_t x = 0; x < width; x++) {
+      if (!covered) {
+        memcpy(dst + 4 * x, bg, 4);
+        continue;
+      }
+      const long ra = sy + i0, rb = sy + i1;
+      const uint8_t *a = (ra >= 0 && ra < rows) ? image + ((size_t)ra * width + x) * 4 : clear;
+      const uint8_t *b = (rb >= 0 && rb < rows) ? image + ((size_t)rb * width + x) * 4 : clear;
+      uint8_t px[4];
+      for (int ch = 0; ch < 4; ch++) {
+        const float fa = (float)a[ch], fb = (float)b[ch];
+        const float d = (fb - fa) * t;
+        px[ch] = (uint8_t)(fa + d + 0.5f);
+      }
+      if (px[3] != 255 && have_bg) {
+        const float fsa = (float)px[3] * (1.0f / 255.0f), fda = (float)bg[3] * (1.0f / 255.0f);
+        const float k = fda * (1.0f - fsa), oa = fsa + k;
+        if (!(oa > 0.0f)) {
+          memset(px, 0, 4);
+        } else {
+          for (int ch = 0; ch < 3; ch++) {
+            const float num = (float)px[ch] * fsa + (float)bg[ch] * k;
+            px[ch] = (uint8_t)(num / oa + 0.5f);
+          }
+          px[3] = (uint8_t)(oa * 255.0f + 0.5f);
+        }
+      }
+      memcpy(dst + 4 * x, px, 4);
+    }
+  }
+}
+
 /* ---- worker: spectrogramWorker.js -------------------------------------------------------- */
 
 /* :195-203 */

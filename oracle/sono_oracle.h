@@ -110,6 +110,18 @@ void orc_plugin_crop_scaled(int bins, double sample_rate, double fmin_hz, double
 void orc_plugin_draw(const uint8_t *frames, size_t width, int bins, const uint8_t *lut,
                      uint8_t *rgba);
 
+/* Placement of the cropped rows on the canvas, :377-381 (channel 0), and whether :357-361 fills first. */
+void orc_plugin_draw_rect(double sample_rate, double fmin_hz, double fmax_hz, int scale, int height, double *dy,
+                          double *dh, int *fill_background);
+/* The fill colour of :358-360 as the canvas stores it. */
+void orc_plugin_background(const double *colormap_last_rgba, uint8_t *rgba);
+/* The drawImage stretch of :380-381 with the engine's own filter (bilinear along y, pixel centres, clamped
+ * edges, float32, round half up).  PARITY UNPINNED: the browser's filter is implementation-defined and the
+ * reference holds no fixture for it; this restates the engine's definition.  image: rows x width RGBA;
+ * canvas: height x width RGBA; background NULL = transparent black. */
+void orc_canvas_draw(const uint8_t *image, size_t width, int rows, long sy, long sh, double dy, double dh,
+                     int height, const uint8_t *background, uint8_t *canvas);
+
 /* ---- worker: spectrogramWorker.js ---------------------------------------------------- */
 
 /* hannWindow, :195-203. */

@@ -112,6 +112,11 @@ SYMBOLS = {
     "sono_resample": (C.c_int, [_VP, _VP, C.c_uint64, C.c_uint32, C.c_uint64, _VP, C.c_int]),
     "sono_colorize": (C.c_int, [_VP, _VP, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, _VP, C.c_int]),
     "sono_frame_peaks": (C.c_int, [_VP, _VP, C.c_uint64, C.c_uint32, _VP, _VP, C.c_int]),
+    "sono_canvas_draw": (C.c_int, [_VP, _VP, C.c_uint64, C.c_uint32, C.c_int64, C.c_int64, C.c_double, C.c_double, C.c_uint32,
+                                   _VP, _VP, C.c_int]),
+    "sono_plugin_draw_rect": (C.c_int, [C.c_double, C.c_double, C.c_double, C.c_uint32, C.c_uint32, C.POINTER(C.c_double),
+                                        C.POINTER(C.c_double), C.POINTER(C.c_int)]),
+    "sono_plugin_background": (C.c_int, [_VP, _VP]),
     "sono_device_malloc": (_VP, [_VP, C.c_uint64]),
     "sono_device_free": (C.c_int, [_VP, _VP]),
     "sono_copy_to_device": (C.c_int, [_VP, _VP, _VP, C.c_uint64]),

@@ -570,6 +570,33 @@ int sono_colorize(sono_ctx* c, const uint8_t* frames, uint64_t width, uint32_t b
   return sono_wait(c);
 }
 
+int sono_canvas_draw(sono_ctx* c, const uint8_t* frames, uint64_t width, uint32_t bins, int64_t sy, int64_t sh, double dy,
+                     double dh, uint32_t height, const uint8_t* background_rgba, uint8_t* canvas, int mem) {
+  if (!c) return SONO_ERR_ARG;
+  if (!frames || !canvas || bins == 0 || dy != dy || dh != dh) return fail(c, SONO_ERR_ARG, "bad canvas_draw arguments");
+  HIP_TRY(c, hipSetDevice(c->device));
+  const uint8_t* din = frames;
+  uint8_t* dout = canvas;
+  const uint64_t out_bytes = width * (uint64_t)height * 4;
+  if (mem == SONO_MEM_HOST) {
+    int rc = ensure(c, &c->d_aux, &c->d_aux_bytes, width * bins);
+    if (rc != SONO_OK) return rc;
+    rc = ensure(c, &c->d_out, &c->d_out_bytes, out_bytes);
+    if (rc != SONO_OK) return rc;
+    HIP_TRY(c, hipMemcpyAsync(c->d_aux, frames, width * bins, hipMemcpyHostToDevice, c->stream));
+    din = (const uint8_t*)c->d_aux;
+    dout = (uint8_t*)c->d_out;
+  }
+  uint32_t bg = 0;
+  if (background_rgba)
+    bg = (uint32_t)background_rgba[0] | (uint32_t)background_rgba[1] << 8 | (uint32_t)background_rgba[2] << 16 |
+         (uint32_t)background_rgba[3] << 24;
+  int rc = launch_canvas_draw(din, width, bins, sy, sh, dy, dh, height, bg, c->have_lut ? c->d_lut : nullptr, dout, c->stream);
+  if (rc != SONO_OK) return fail(c, rc, "canvas_draw launch failed");
+  if (mem == SONO_MEM_HOST && out_bytes) HIP_TRY(c, hipMemcpyAsync(canvas, dout, out_bytes, hipMemcpyDeviceToHost, c->stream));
+  return sono_wait(c);
+}
+
 int sono_frame_peaks(sono_ctx* c, const uint8_t* idx, uint64_t frames, uint32_t bins, int32_t* peak_bin, uint8_t* peak_idx,
                      int mem) {
   if (!c) return SONO_ERR_ARG;

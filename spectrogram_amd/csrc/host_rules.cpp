@@ -244,6 +244,36 @@ int sono_plugin_crop_scaled(uint32_t bins, double sample_rate, double fmin, doub
   return SONO_OK;
 }
 
+int sono_plugin_draw_rect(double sample_rate, double fmin, double fmax, uint32_t scale, uint32_t height, double* dy, double* dh,
+                          int* fill_background) {
+  if (!dy || !dh || !fill_background || !(sample_rate > 0) || scale > SONO_FSCALE_ERB) return SONO_ERR_ARG;
+  (void)fmin;
+  const double nyq = sample_rate / 2;
+  if (fmax == 0) fmax = nyq;
+  const double f = sono_hz_to_scale(scale, fmax) / sono_hz_to_scale(scale, nyq);  // :378-379
+  const double p = f < 1 ? f : 1;
+  *dy = (double)height * (1 - p / f);  // :381 for channel h = 0
+  *dh = (double)height * p / f;
+  *fill_background = fmax > nyq ? 1 : 0;  // :357
+  return SONO_OK;
+}
+
+int sono_plugin_background(const double* last, uint8_t* rgba) {  // spectrogram.esm.js:358-360
+  if (!last || !rgba) return SONO_ERR_ARG;
+  if (std::isnan(last[0]) || std::isnan(last[1]) || std::isnan(last[2]) || std::isnan(last[3])) {
+    rgba[0] = rgba[1] = rgba[2] = 0;  // "rgba(NaN, ...)" does not parse: fillStyle keeps its default, opaque black
+    rgba[3] = 255;
+    return SONO_OK;
+  }
+  for (int ch = 0; ch < 3; ch++) {
+    const double v = last[ch] < 0 ? 0 : last[ch] > 255 ? 255 : last[ch];
+    rgba[ch] = (uint8_t)ecma_round(v);
+  }
+  const double a = last[3] < 0 ? 0 : last[3] > 1 ? 1 : last[3];
+  rgba[3] = (uint8_t)ecma_round(a * 255);
+  return SONO_OK;
+}
+
 int sono_plugin_lut(const double* cm, uint8_t* lut) {  // spectrogram.esm.js:262-271
   if (!cm || !lut) return SONO_ERR_ARG;
   for (int i = 0; i < 1024; i++) lut[i] = ecma_uint8_clamp(ecma_round(255 * cm[i]));

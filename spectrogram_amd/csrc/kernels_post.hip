@@ -122,6 +122,129 @@ int launch_colorize(const uint8_t* frames, uint64_t ncols, uint32_t bins, uint32
 }
 
 // ------------------------------------------------------------------------------------------
+// The canvas step of drawSpectrogram, spectrogram.esm.js:357-361,377-381: the cropped rows
+// [sy, sy + sh) of the flipped LUT image are stretched over canvas rows [dy, dy + dh) of a
+// `height`-row canvas; everything else keeps the background.  The browser's drawImage filter is
+// implementation-defined; this one is bilinear along y with clamped edges, sampled at pixel centres:
+//   v = (y + 0.5 - dy) * sh / dh - 0.5 clamped to [0, sh - 1], i0 = floor(v), t = float(v - i0),
+//   channel = floor(a + (b - a) * t + 0.5) in float32 (no fused multiply-add),
+// canvas rows whose centre lies outside [dy, dy + dh) are not covered.  Source rows outside the
+// image are transparent black (createImageBitmap's rule for a crop rectangle beyond the source).
+// A pixel with alpha < 255 is composited over the background (source-over, straight alpha, float32).
+struct CanvasRow {
+  int64_t i0, i1;  // rows of the crop window, or i0 < 0: not covered
+  float t;
+};
+__host__ __device__ inline CanvasRow canvas_row(uint32_t y, int64_t sh, double dy, double dh) {
+  CanvasRow r = {-1, -1, 0.0f};
+  const double yc = (double)y + 0.5;
+  if (sh <= 0 || !(dh > 0) || !(yc >= dy) || !(yc < dy + dh)) return r;
+  double v = (yc - dy) * ((double)sh / dh) - 0.5;
+  if (v < 0) v = 0;
+  if (v > (double)(sh - 1)) v = (double)(sh - 1);
+  const double f = floor(v);
+  r.i0 = (int64_t)f;
+  r.i1 = r.i0 + 1 < sh ? r.i0 + 1 : sh - 1;
+  r.t = (float)(v - f);
+  return r;
+}
+
+__device__ inline uint32_t canvas_mix(uint32_t a, uint32_t b, float t, uint32_t bg) {
+  uint32_t px = 0;
+#pragma unroll
+  for (int ch = 0; ch < 4; ++ch) {
+    const float fa = (float)((a >> (8 * ch)) & 255u), fb = (float)((b >> (8 * ch)) & 255u);
+    const float d = (fb - fa) * t;
+    px |= (uint32_t)(fa + d + 0.5f) << (8 * ch);
+  }
+  const uint32_t sa = px >> 24;
+  if (sa == 255u || bg == 0u) return px;
+  // source-over on the background colour
+  const float fsa = (float)sa * (1.0f / 255.0f), fda = (float)(bg >> 24) * (1.0f / 255.0f);
+  const float k = fda * (1.0f - fsa), oa = fsa + k;
+  if (!(oa > 0.0f)) return 0u;
+  uint32_t o = (uint32_t)(oa * 255.0f + 0.5f) << 24;
+#pragma unroll
+  for (int ch = 0; ch < 3; ++ch) {
+    const float sc = (float)((px >> (8 * ch)) & 255u), dc = (float)((bg >> (8 * ch)) & 255u);
+    const float num = sc * fsa + dc * k;
+    o |= (uint32_t)(num / oa + 0.5f) << (8 * ch);
+  }
+  return o;
+}
+
+constexpr int kCanvasBand = 32;  // canvas rows per workgroup
+
+// frames: [width][bins] uint8 (after resample).  One workgroup: `cols` image columns x kCanvasBand
+// canvas rows; the source bytes it needs (`span` crop rows at most, host-computed) go through LDS as
+// [column][row - lo], read along bins and written along columns.
+__global__ __launch_bounds__(256) void canvas_draw_kernel(const uint8_t* __restrict__ frames, uint64_t width, uint32_t bins,
+                                                         int64_t sy, int64_t sh, double dy, double dh, uint32_t height,
+                                                         uint32_t background, const uint32_t* __restrict__ lut,
+                                                         uint32_t cols, uint32_t span, uint32_t* __restrict__ canvas) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t src[];  // [cols][span]
+  const uint64_t x0 = (uint64_t)blockIdx.x * cols;
+  const uint32_t ncol = (uint32_t)min((uint64_t)cols, width - x0);
+  const uint32_t y0 = blockIdx.y * kCanvasBand, y1 = min(height, y0 + kCanvasBand);
+  // crop rows this band touches: the row map is monotonic in y
+  int64_t lo = -1, hi = -1;
+  for (uint32_t y = y0; y < y1; ++y) {
+    const CanvasRow r = canvas_row(y, sh, dy, dh);
+    if (r.i0 < 0) continue;
+    if (lo < 0) lo = r.i0;
+    hi = r.i1;
+  }
+  const uint32_t nrow = lo < 0 ? 0u : (uint32_t)(hi - lo + 1);  // <= span by the host's bound
+  for (uint32_t i = threadIdx.x; i < ncol * nrow; i += 256) {
+    const uint32_t c = i / nrow, k = i - c * nrow;
+    const int64_t row = sy + lo + k;  // row of the flipped image: bin bins-1-row
+    src[c * span + k] = (row >= 0 && row < (int64_t)bins) ? frames[(x0 + c) * bins + (bins - 1 - (uint32_t)row)] : 0;
+  }
+  __syncthreads();
+  for (uint32_t i = threadIdx.x; i < ncol * (y1 - y0); i += 256) {
+    const uint32_t yy = i / ncol, c = i - yy * ncol, y = y0 + yy;
+    const CanvasRow r = canvas_row(y, sh, dy, dh);
+    uint32_t px = background;
+    if (r.i0 >= 0) {
+      const int64_t ra = sy + r.i0, rb = sy + r.i1;
+      const uint32_t ia = src[c * span + (uint32_t)(r.i0 - lo)], ib = src[c * span + (uint32_t)(r.i1 - lo)];
+      const uint32_t a = (ra >= 0 && ra < (int64_t)bins) ? (lut ? lut[ia] : (ia | (ia << 8) | (ia << 16) | 0xff000000u)) : 0u;
+      const uint32_t b = (rb >= 0 && rb < (int64_t)bins) ? (lut ? lut[ib] : (ib | (ib << 8) | (ib << 16) | 0xff000000u)) : 0u;
+      px = canvas_mix(a, b, r.t, background);
+    }
+    canvas[(uint64_t)y * width + x0 + c] = px;
+  }
+}
+
+int launch_canvas_draw(const uint8_t* frames, uint64_t width, uint32_t bins, int64_t sy, int64_t sh, double dy, double dh,
+                       uint32_t height, uint32_t background, const uint32_t* lut, uint8_t* canvas, void* stream_v) {
+  if (width == 0 || height == 0) return SONO_OK;
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_v);
+  // widest run of crop rows any band of kCanvasBand canvas rows touches
+  uint32_t span = 1;
+  for (uint32_t y0 = 0; y0 < height; y0 += kCanvasBand) {
+    int64_t lo = -1, hi = -1;
+    for (uint32_t y = y0; y < y0 + kCanvasBand && y < height; ++y) {
+      const CanvasRow r = canvas_row(y, sh, dy, dh);
+      if (r.i0 < 0) continue;
+      if (lo < 0) lo = r.i0;
+      hi = r.i1;
+    }
+    if (lo >= 0 && (uint64_t)(hi - lo + 1) > span) span = (uint32_t)(hi - lo + 1);
+  }
+  span = (span + 3u) & ~3u;
+  uint32_t cols = 64;
+  while (cols > 1 && (uint64_t)cols * span > 48u * 1024u) cols >>= 1;
+  if ((uint64_t)cols * span > 64u * 1024u) return SONO_ERR_ARG;
+  const uint64_t gx = (width + cols - 1) / cols;
+  const uint32_t gy = (height + kCanvasBand - 1) / kCanvasBand;
+  if (gx > 0x7fffffffull || gy > 65535u) return SONO_ERR_ARG;
+  hipLaunchKernelGGL(canvas_draw_kernel, dim3((uint32_t)gx, gy), dim3(256), cols * span, stream, frames, width, bins, sy, sh,
+                     dy, dh, height, background, lut, cols, span, reinterpret_cast<uint32_t*>(canvas));
+  return hipGetLastError() == hipSuccess ? SONO_OK : SONO_ERR_DEVICE;
+}
+
+// ------------------------------------------------------------------------------------------
 // Per-frame peak: first bin holding the maximum index (strict > in ascending bin order, the
 // rule of spectrogram.esm.js:196).  One wavefront per frame.
 __global__ __launch_bounds__(256) void frame_peaks_kernel(const uint8_t* __restrict__ idx, uint64_t frames, uint32_t bins,

@@ -198,6 +198,17 @@ class Engine:
         self._check(self._lib.sono_colorize(self._ctx, F.ptr(frames), W, B, int(row0), int(rows), F.ptr(out), F.MEM_HOST))
         return out
 
+    def canvas_draw(self, frames, sy, sh, dy, dh, height, background=None):
+        """[width][bins] uint8 columns -> [height][width][4] canvas: LUT + flip, rows [sy, sy + sh) stretched
+        over canvas rows [dy, dy + dh) (spectrogram.esm.js:357-381 with the engine's bilinear filter)."""
+        frames = np.ascontiguousarray(frames, np.uint8)
+        W, B = frames.shape
+        out = np.empty((int(height), W, 4), np.uint8)
+        bg = None if background is None else np.ascontiguousarray(background, np.uint8).reshape(4)
+        self._check(self._lib.sono_canvas_draw(self._ctx, F.ptr(frames), W, B, int(sy), int(sh), float(dy), float(dh),
+                                               int(height), None if bg is None else F.ptr(bg), F.ptr(out), F.MEM_HOST))
+        return out
+
     def frame_peaks(self, idx):
         idx = np.ascontiguousarray(idx, np.uint8)
         Fr, B = idx.shape
@@ -263,6 +274,26 @@ def plugin_crop_scaled(bins, sample_rate, fmin_hz, fmax_hz, scale):
     if rc != F.OK:
         raise F.SonoError(rc, "bad crop arguments")
     return sy.value, sh.value
+
+
+def plugin_draw_rect(sample_rate, fmin_hz, fmax_hz, scale, height):
+    """(dy, dh, fill_background) of drawSpectrogram's drawImage call, spectrogram.esm.js:357,377-381."""
+    dy, dh, fill = C.c_double(0), C.c_double(0), C.c_int(0)
+    rc = F.lib().sono_plugin_draw_rect(float(sample_rate), float(fmin_hz), float(fmax_hz), F.FREQ_SCALES[scale], int(height),
+                                       C.byref(dy), C.byref(dh), C.byref(fill))
+    if rc != F.OK:
+        raise F.SonoError(rc, "bad draw_rect arguments")
+    return dy.value, dh.value, bool(fill.value)
+
+
+def plugin_background(colormap_last):
+    """The fill colour of spectrogram.esm.js:358-360 as four bytes."""
+    last = np.ascontiguousarray(colormap_last, np.float64).reshape(4)
+    out = np.empty(4, np.uint8)
+    rc = F.lib().sono_plugin_background(F.ptr(last), F.ptr(out))
+    if rc != F.OK:
+        raise F.SonoError(rc, "bad background arguments")
+    return out
 
 
 def plugin_crop(bins, sample_rate, fmin_hz, fmax_hz):

@@ -147,6 +147,24 @@ class Spectrogram:
         sy0, sy1 = max(0, sy), max(0, min(rgba.shape[0], sy + sh))
         return rgba[sy0:sy1]
 
+    def drawCanvas(self, frames, width):
+        """The whole of drawSpectrogram (:345-388) for one channel: the [height][width][4] canvas.  The
+        browser's drawImage resampling filter is implementation-defined; the engine's is bilinear along
+        y between pixel centres (see sono_canvas_draw)."""
+        cols = self.resample(frames, width)
+        eng = self._any_engine()
+        eng.set_colormap(self._colorMapUint)
+        sr = self.buffer.sampleRate
+        sy, sh = self.crop_rows(cols.shape[1])
+        dy, dh, fill = E.plugin_draw_rect(sr, self.frequencyMin, self.frequencyMax, self.scale, self.height)
+        bg = E.plugin_background(self.colorMap[len(self.colorMap) - 1]) if fill else None      # :357-361
+        return eng.canvas_draw(cols, sy, sh, dy, dh, self.height, bg)
+
+    def renderCanvas(self, buffer, width):
+        """render() (:336-344) down to the canvas pixels, channel 0."""
+        frames = self.getFrequencies(buffer, canvas_width=width)[0]
+        return self.drawCanvas(frames, width)
+
     def destroy(self):
         for e in self._engines.values():
             e.close()

@@ -537,3 +537,67 @@ def test_plugin_scaled_get_frequencies(case):
         d = cyc_diff(got, ref)
         assert got.shape == ref.shape and d.max() <= 1 and (d != 0).mean() <= frac, (arith, d.max(), (d != 0).mean())
     assert np.array_equal(oracle.plugin_get_frequencies_scaled(x, case["N"], case["noverlap"], case["scale"], sr).shape, ref.shape)
+
+
+# ------------------------------------------------------------------ the canvas step of drawSpectrogram (:357-381)
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", G.cases("plugin_render"), ids=lambda c: c["id"])
+@pytest.mark.parametrize("height", [200, 800, 37])
+def test_plugin_canvas_matches_the_filter_definition(case, height):
+    """The image the reference hands to createImageBitmap is pinned (fixtures); the stretch onto the canvas is the
+    browser's, so the kernel is compared bit for bit with the checker's restatement of the engine's own filter
+    applied to the reference's image."""
+    x, sr = G.signal(case["signal"]), G.sample_rate(case["signal"])
+    name = case["colormap"]
+    cm = G.colormap(name).tolist() if name in ("default", "rainbow") else name
+    p = Spectrogram.create({"fftSamples": case["N"], "noverlap": case["noverlap"], "colorMap": cm, "scale": "linear",
+                            "frequencyMin": case["fmin"], "frequencyMax": case["fmax"], "windowFunc": case["window"],
+                            "arith": "exact", "height": height})
+    canvas = p.renderCanvas(AudioBuffer(x, sr), case["out_width"])
+    ref_img = G.load(case["rgba"], np.uint8).reshape(case["image_height"], case["image_width"], 4)
+    sy, sh = case["crop"]["sy"], case["crop"]["sh"]
+    dy, dh, fill = oracle.plugin_draw_rect(sr, case["fmin"], case["fmax"], "linear", height)
+    bg = oracle.plugin_background(p.colorMap[-1]) if fill else None
+    want = oracle.canvas_draw(ref_img, sy, sh, dy, dh, height, bg)
+    assert canvas.shape == (height, case["out_width"], 4)
+    assert np.array_equal(canvas, want)
+    p.destroy()
+
+
+@pytest.mark.gpu
+def test_canvas_draw_edges():
+    """Identity stretch copies the rows; frequencyMax above Nyquist leaves a background band on top; a crop window
+    reaching past the image reads transparent rows; translucent colours go over the background."""
+    rng = np.random.default_rng(5)
+    W, B = 333, 256
+    cols = rng.integers(0, 256, (W, B), dtype=np.uint8)
+    lut = rng.integers(0, 256, (256, 4), dtype=np.uint8)
+    lut[:, 3] = 255
+    eng = plugin_engine(512, 128, F.ARITH_FAST_F32)
+    eng.set_colormap(lut.reshape(-1))
+    img = oracle.plugin_draw(cols, lut.reshape(-1))
+    # identity: 100 rows from row 20 onto a 100-row canvas
+    got = eng.canvas_draw(cols, 20, 100, 0.0, 100.0, 100)
+    assert np.array_equal(got, img[20:120])
+    # sweep of placements, sizes, backgrounds, against the definition
+    bg = np.array([1, 0, 1, 255], np.uint8)
+    for sy, sh, dy, dh, height, back in [(0, 256, 0.0, 800.0, 800, None), (0, 256, 160.0, 640.0, 800, bg),
+                                         (13, 77, 3.25, 41.5, 64, bg), (-5, 300, 0.0, 50.0, 50, None),
+                                         (0, 256, 0.0, 31.0, 31, None), (40, 0, 0.0, 10.0, 10, bg), (0, 1, 2.0, 5.0, 9, None)]:
+        got = eng.canvas_draw(cols, sy, sh, dy, dh, height, back)
+        want = oracle.canvas_draw(img, sy, sh, dy, dh, height, back)
+        assert np.array_equal(got, want), (sy, sh, dy, dh, height)
+    # translucent colour map over a translucent background
+    lut2 = lut.copy()
+    lut2[:, 3] = rng.integers(0, 256, 256, dtype=np.uint8)
+    eng.set_colormap(lut2.reshape(-1))
+    img2 = oracle.plugin_draw(cols, lut2.reshape(-1))
+    bg2 = np.array([200, 100, 50, 128], np.uint8)
+    got = eng.canvas_draw(cols, -3, 262, 7.5, 120.0, 140, bg2)
+    assert np.array_equal(got, oracle.canvas_draw(img2, -3, 262, 7.5, 120.0, 140, bg2))
+    # large transform: many crop rows per canvas row (narrower column tiles)
+    cols3 = rng.integers(0, 256, (70, 4096), dtype=np.uint8)
+    img3 = oracle.plugin_draw(cols3, lut2.reshape(-1))
+    got = eng.canvas_draw(cols3, 0, 4096, 0.0, 64.0, 64, bg2)
+    assert np.array_equal(got, oracle.canvas_draw(img3, 0, 4096, 0.0, 64.0, 64, bg2))
+    eng.close()

@@ -184,3 +184,42 @@ def test_scale_rules_match_reference():
     for r in grid["rows"]:
         assert E.plugin_crop_scaled(r["N"] // 2, r["sr"], r["fmin"], r["fmax"], r["scale"]) == (r["sy"], r["sh"]), r
     assert E.plugin_crop_scaled(512, 384000, 10000, 128000, "linear") == E.plugin_crop(512, 384000, 10000, 128000)
+
+
+def test_canvas_placement_rules():
+    """drawImage rectangle and background of drawSpectrogram (spectrogram.esm.js:357-361,377-381)."""
+    import oracle
+    # frequencyMax at or below Nyquist: the rows fill the canvas, no fill
+    f = 128000 / 192000
+    assert E.plugin_draw_rect(384000, 10000, 128000, "linear", 800) == (800 * (1 - f / f), 800 * f / f, False)   # s*p/f, left to right
+    assert E.plugin_draw_rect(384000, 0, 0, "linear", 200) == (0.0, 200.0, False)
+    # above Nyquist: p = 1, f = fmax / nyquist; the image sits at the bottom, the top band keeps the fill
+    dy, dh, fill = E.plugin_draw_rect(256000, 10000, 160000, "linear", 800)
+    assert fill and dh == 800 * 1 / (160000 / 128000) and dy == 800 * (1 - 1 / (160000 / 128000))
+    for scale in ("linear", "mel", "logarithmic", "bark", "erb"):
+        for sr, f0, f1, h in [(384000, 10000, 128000, 800), (256000, 0, 200000, 512), (44100, 100, 30000, 200), (48000, 0, 0, 37)]:
+            assert E.plugin_draw_rect(sr, f0, f1, scale, h) == oracle.plugin_draw_rect(sr, f0, f1, scale, h), (scale, sr, f1)
+    # "rgba(r, g, b, a)" built from 0..1 colour-map numbers: channels round to 0 or 1
+    assert E.plugin_background([0.98, 0.5, 0.2, 1]).tolist() == [1, 1, 0, 255]
+    assert E.plugin_background([0.49, 300, -4, 0.5]).tolist() == [0, 255, 0, 128]
+    assert E.plugin_background([float("nan"), 0, 0, 1]).tolist() == [0, 0, 0, 255]
+    for last in ([0.98, 0.5, 0.2, 1], [0.49, 300, -4, 0.5], [float("nan"), 0, 0, 1], [0, 0, 0, 0]):
+        assert np.array_equal(E.plugin_background(last), oracle.plugin_background(last))
+
+
+def test_canvas_filter_definition_properties():
+    """The checker's restatement of the canvas filter: identity placement copies rows, a two-fold stretch
+    interpolates half way between neighbouring rows, uncovered rows keep the background."""
+    import oracle
+    rng = np.random.default_rng(2)
+    img = rng.integers(0, 256, (40, 9, 4), dtype=np.uint8)
+    img[..., 3] = 255
+    assert np.array_equal(oracle.canvas_draw(img, 5, 30, 0.0, 30.0, 30), img[5:35])
+    bg = np.array([9, 8, 7, 255], np.uint8)
+    out = oracle.canvas_draw(img, 0, 40, 10.0, 80.0, 100, bg)
+    assert (out[:10] == bg).all() and (out[90:] == bg).all()
+    # canvas row 10 + 2k + 1 has its centre 0.25 / 0.75 of the way between rows k and k + 1
+    a, b = img[3].astype(np.float32), img[4].astype(np.float32)
+    assert np.array_equal(out[10 + 7], np.floor(a + (b - a) * np.float32(0.25) + np.float32(0.5)).astype(np.uint8))
+    assert np.array_equal(out[10 + 8], np.floor(a + (b - a) * np.float32(0.75) + np.float32(0.5)).astype(np.uint8))
+    assert np.array_equal(out[10], img[0]) and np.array_equal(out[89], img[39])     # clamped edges
