@@ -270,6 +270,9 @@ int sono_host_free(void* p);
 /* resample (spectrogram.esm.js:595-640): [in_frames][bins] uint8 -> [out_width][bins] uint8. */
 int sono_resample(sono_ctx* ctx, const uint8_t* in, uint64_t in_frames, uint32_t bins, uint64_t out_width,
                   uint8_t* out, int mem);
+/* Columns [col0, col0 + ncols) of that result only (a tile of a zoomed view): out is [ncols][bins]. */
+int sono_resample_cols(sono_ctx* ctx, const uint8_t* in, uint64_t in_frames, uint32_t bins, uint64_t out_width, uint64_t col0,
+                       uint64_t ncols, uint8_t* out, int mem);
 
 /* LUT + vertical flip + row window of drawSpectrogram (spectrogram.esm.js:366-380):
  * [width][bins] uint8 -> rows [row0, row0+rows) of the [bins][width] RGBA image. */

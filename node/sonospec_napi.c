@@ -761,6 +761,41 @@ static napi_value js_canvas_draw(napi_env env, napi_callback_info info) {
   return rc == SONO_OK ? result : throw_ctx(env, h, rc);
 }
 
+/* resampleColsDevice(handle, inPtr, frames, bins, outWidth, col0, ncols, outPtr): device to device */
+static napi_value js_resample_cols_device(napi_env env, napi_callback_info info) {
+  ARGS(env, info, 8);
+  handle_t* h = get_handle(env, argv[0]);
+  void *in, *out;
+  uint64_t F, W, col0, ncols;
+  uint32_t B;
+  if (!h || !get_ptr(env, argv[1], &in) || !get_u64(env, argv[2], &F) || !get_u32(env, argv[3], &B) || !get_u64(env, argv[4], &W) ||
+      !get_u64(env, argv[5], &col0) || !get_u64(env, argv[6], &ncols) || !get_ptr(env, argv[7], &out))
+    return throw_msg(env, "resampleColsDevice(handle, inPtr, frames, bins, outWidth, col0, ncols, outPtr)");
+  int rc = sono_resample_cols(h->ctx, (const uint8_t*)in, F, B, W, col0, ncols, (uint8_t*)out, SONO_MEM_DEVICE);
+  return rc == SONO_OK ? NULL : throw_ctx(env, h, rc);
+}
+
+/* canvasDrawDevice(handle, colsPtr, width, bins, sy, sh, dy, dh, height, background Uint8Array(4) | null, outPtr) */
+static napi_value js_canvas_draw_device(napi_env env, napi_callback_info info) {
+  ARGS(env, info, 11);
+  handle_t* h = get_handle(env, argv[0]);
+  void *in, *out;
+  uint64_t W;
+  uint32_t B, height;
+  double sy, sh, dy, dh;
+  if (!h || !get_ptr(env, argv[1], &in) || !get_u64(env, argv[2], &W) || !get_u32(env, argv[3], &B) || !get_f64(env, argv[4], &sy) ||
+      !get_f64(env, argv[5], &sh) || !get_f64(env, argv[6], &dy) || !get_f64(env, argv[7], &dh) || !get_u32(env, argv[8], &height) ||
+      !get_ptr(env, argv[10], &out))
+    return throw_msg(env, "canvasDrawDevice(handle, colsPtr, width, bins, sy, sh, dy, dh, height, background, outPtr)");
+  napi_typedarray_type t;
+  void* bgp = NULL;
+  int64_t bn = ta_data(env, argv[9], &t, &bgp);
+  if (bn < 0 || (bgp && bn < 4)) return throw_msg(env, "canvasDrawDevice: background must hold 4 bytes or be null");
+  int rc = sono_canvas_draw(h->ctx, (const uint8_t*)in, W, B, (int64_t)sy, (int64_t)sh, dy, dh, height, (const uint8_t*)bgp, (uint8_t*)out,
+                            SONO_MEM_DEVICE);
+  return rc == SONO_OK ? NULL : throw_ctx(env, h, rc);
+}
+
 /* ---- overlapped per-file batches: page-locked host buffers + host-async transform ------------- */
 
 static void pinned_finalize(napi_env env, void* data, void* hint) {
@@ -849,6 +884,8 @@ static napi_value init(napi_env env, napi_value exports) {
   EXPORT("pluginDrawRect", js_plugin_draw_rect);
   EXPORT("pluginBackground", js_plugin_background);
   EXPORT("canvasDraw", js_canvas_draw);
+  EXPORT("resampleColsDevice", js_resample_cols_device);
+  EXPORT("canvasDrawDevice", js_canvas_draw_device);
   EXPORT("wavParse", js_wav_parse);
   EXPORT("wavGuano", js_wav_guano);
   EXPORT("guanoFields", js_guano_fields);

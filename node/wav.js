@@ -45,4 +45,24 @@ function pcmSamples(file) {
   return { raw: b.subarray(w.dataOffset, w.dataOffset + w.frames * w.blockAlign), info: w };
 }
 
-module.exports = { getWavSampleRate, getWavDuration, extractGuanoMetadata, parseGuanoMetadata, cropWavBlob, acceptFile, pcmSamples };
+// One channel of the data chunk as Float32Array, on the host: v / 2^(bits-1) for integer PCM (8-bit is offset binary),
+// float32 as stored -- the convention of the device conversion (sono_pcm_to_f32).
+function channelData(file, channel = 0) {
+  const { raw, info: w } = pcmSamples(file);
+  const bits = w.bitsPerSample, step = w.blockAlign, out = new Float32Array(w.frames);
+  const dv = new DataView(raw.buffer, raw.byteOffset, raw.byteLength), o0 = channel * (bits >> 3);
+  if (channel < 0 || channel >= w.channels) throw new RangeError('no such channel');
+  if (w.formatTag === 3 && bits === 32) for (let i = 0; i < w.frames; i++) out[i] = dv.getFloat32(i * step + o0, true);
+  else if (w.formatTag === 1 && bits === 16) for (let i = 0; i < w.frames; i++) out[i] = dv.getInt16(i * step + o0, true) / 32768;
+  else if (w.formatTag === 1 && bits === 8) for (let i = 0; i < w.frames; i++) out[i] = (dv.getUint8(i * step + o0) - 128) / 128;
+  else if (w.formatTag === 1 && bits === 24)
+    for (let i = 0; i < w.frames; i++) {
+      const p = i * step + o0;
+      out[i] = ((dv.getUint8(p) | (dv.getUint8(p + 1) << 8) | (dv.getInt8(p + 2) << 16))) / 8388608;
+    }
+  else if (w.formatTag === 1 && bits === 32) for (let i = 0; i < w.frames; i++) out[i] = dv.getInt32(i * step + o0, true) / 2147483648;
+  else throw new Error('unsupported PCM format (tag ' + w.formatTag + ', ' + bits + ' bits)');
+  return out;
+}
+
+module.exports = { getWavSampleRate, getWavDuration, extractGuanoMetadata, parseGuanoMetadata, cropWavBlob, acceptFile, pcmSamples, channelData };

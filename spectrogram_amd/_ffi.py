@@ -110,6 +110,7 @@ SYMBOLS = {
     "sono_stft_async": (C.c_int, [_VP, _VP, C.c_uint64, _VP, C.c_uint64]),
     "sono_wait": (C.c_int, [_VP]),
     "sono_resample": (C.c_int, [_VP, _VP, C.c_uint64, C.c_uint32, C.c_uint64, _VP, C.c_int]),
+    "sono_resample_cols": (C.c_int, [_VP, _VP, C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint64, C.c_uint64, _VP, C.c_int]),
     "sono_colorize": (C.c_int, [_VP, _VP, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, _VP, C.c_int]),
     "sono_frame_peaks": (C.c_int, [_VP, _VP, C.c_uint64, C.c_uint32, _VP, _VP, C.c_int]),
     "sono_canvas_draw": (C.c_int, [_VP, _VP, C.c_uint64, C.c_uint32, C.c_int64, C.c_int64, C.c_double, C.c_double, C.c_uint32,

@@ -525,26 +525,31 @@ void* sono_host_malloc(uint64_t bytes) {
 
 int sono_host_free(void* p) { return (!p || hipHostFree(p) == hipSuccess) ? SONO_OK : SONO_ERR_DEVICE; }
 
-int sono_resample(sono_ctx* c, const uint8_t* in, uint64_t F, uint32_t bins, uint64_t W, uint8_t* out, int mem) {
+int sono_resample_cols(sono_ctx* c, const uint8_t* in, uint64_t F, uint32_t bins, uint64_t W, uint64_t col0, uint64_t ncols,
+                       uint8_t* out, int mem) {
   if (!c) return SONO_ERR_ARG;
-  if (!in || !out || bins == 0) return fail(c, SONO_ERR_ARG, "bad resample arguments");
+  if (!in || !out || bins == 0 || col0 > W || ncols > W - col0) return fail(c, SONO_ERR_ARG, "bad resample arguments");
   HIP_TRY(c, hipSetDevice(c->device));
   const uint8_t* din = in;
   uint8_t* dout = out;
   if (mem == SONO_MEM_HOST) {
     int rc = ensure(c, &c->d_aux, &c->d_aux_bytes, F * bins);
     if (rc != SONO_OK) return rc;
-    rc = ensure(c, &c->d_out, &c->d_out_bytes, W * bins);
+    rc = ensure(c, &c->d_out, &c->d_out_bytes, ncols * bins);
     if (rc != SONO_OK) return rc;
     HIP_TRY(c, hipMemcpyAsync(c->d_aux, in, F * bins, hipMemcpyHostToDevice, c->stream));
     din = (const uint8_t*)c->d_aux;
     dout = (uint8_t*)c->d_out;
   }
-  if (F == 0) HIP_TRY(c, hipMemsetAsync(dout, 0, W * bins, c->stream));
-  int rc = launch_resample(din, F, bins, W, dout, c->stream);
+  if (F == 0 && ncols) HIP_TRY(c, hipMemsetAsync(dout, 0, ncols * bins, c->stream));
+  int rc = launch_resample(din, F, bins, W, col0, ncols, dout, c->stream);
   if (rc != SONO_OK) return fail(c, rc, "resample launch failed");
-  if (mem == SONO_MEM_HOST) HIP_TRY(c, hipMemcpyAsync(out, dout, W * bins, hipMemcpyDeviceToHost, c->stream));
+  if (mem == SONO_MEM_HOST && ncols) HIP_TRY(c, hipMemcpyAsync(out, dout, ncols * bins, hipMemcpyDeviceToHost, c->stream));
   return sono_wait(c);
+}
+
+int sono_resample(sono_ctx* c, const uint8_t* in, uint64_t F, uint32_t bins, uint64_t W, uint8_t* out, int mem) {
+  return sono_resample_cols(c, in, F, bins, W, 0, W, out, mem);
 }
 
 int sono_colorize(sono_ctx* c, const uint8_t* frames, uint64_t width, uint32_t bins, uint32_t row0, uint32_t rows,

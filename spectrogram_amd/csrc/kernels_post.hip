@@ -13,9 +13,9 @@ namespace sono {
 // no overlap, so only [n0, n1) (two frames of margin) are tested, with the reference's own
 // double expressions deciding membership and weight, in ascending n like its contrib list.
 __global__ __launch_bounds__(256) void resample_kernel(const uint8_t* __restrict__ in, uint64_t F, uint32_t bins,
-                                                      uint64_t W, double invIn, double invOut,
+                                                      uint64_t W, uint64_t col0, double invIn, double invOut,
                                                       uint8_t* __restrict__ out) {
-  const uint64_t a = blockIdx.x;
+  const uint64_t a = col0 + blockIdx.x;  // column of the W-wide result; row blockIdx.x of `out`
   const double o = (double)a * invOut, l = o + invOut;
   double lo_f = floor((double)a * (double)F / (double)W) - 2;
   double hi_f = ceil((double)(a + 1) * (double)F / (double)W) + 2;
@@ -35,15 +35,16 @@ __global__ __launch_bounds__(256) void resample_kernel(const uint8_t* __restrict
     }
     uint32_t v = 0;
     if (any && fabs(accum) < 1e15) v = (uint32_t)((long long)trunc(accum) & 255);  // Uint8Array store
-    out[a * bins + u] = (uint8_t)v;
+    out[(uint64_t)blockIdx.x * bins + u] = (uint8_t)v;
   }
 }
 
-int launch_resample(const uint8_t* in, uint64_t F, uint32_t bins, uint64_t W, uint8_t* out, void* stream_v) {
-  if (W == 0 || F == 0) return SONO_OK;
-  if (W > 0x7fffffffull) return SONO_ERR_ARG;
+int launch_resample(const uint8_t* in, uint64_t F, uint32_t bins, uint64_t W, uint64_t col0, uint64_t ncols, uint8_t* out,
+                    void* stream_v) {
+  if (W == 0 || F == 0 || ncols == 0) return SONO_OK;
+  if (ncols > 0x7fffffffull || col0 > W || ncols > W - col0) return SONO_ERR_ARG;
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_v);
-  hipLaunchKernelGGL(resample_kernel, dim3((uint32_t)W), dim3(256), 0, stream, in, F, bins, W, 1.0 / (double)F,
+  hipLaunchKernelGGL(resample_kernel, dim3((uint32_t)ncols), dim3(256), 0, stream, in, F, bins, W, col0, 1.0 / (double)F,
                      1.0 / (double)W, out);
   return hipGetLastError() == hipSuccess ? SONO_OK : SONO_ERR_DEVICE;
 }

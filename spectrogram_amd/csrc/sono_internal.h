@@ -55,8 +55,8 @@ void build_fast_table_1024(std::vector<float>& t);
 int launch_stft_mw(const StftParams& p, void* hip_stream);
 bool mw_u8_available(const StftParams& p);
 // kernels_post.hip
-int launch_resample(const uint8_t* in, uint64_t in_frames, uint32_t bins, uint64_t out_width, uint8_t* out,
-                    void* hip_stream);
+int launch_resample(const uint8_t* in, uint64_t in_frames, uint32_t bins, uint64_t out_width, uint64_t col0, uint64_t ncols,
+                    uint8_t* out, void* hip_stream);
 int launch_colorize(const uint8_t* frames, uint64_t ncols, uint32_t bins, uint32_t row0, uint32_t rows,
                     const uint32_t* lut, uint8_t* rgba, uint64_t img_width, uint64_t col0, void* hip_stream);
 int launch_canvas_draw(const uint8_t* frames, uint64_t width, uint32_t bins, int64_t sy, int64_t sh, double dy, double dh,

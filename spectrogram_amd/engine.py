@@ -149,6 +149,21 @@ class Engine:
         self._check(self._lib.sono_copy_to_host(self._ctx, F.ptr(arr), C.c_void_p(ptr), arr.nbytes))
         return arr
 
+    def copy_to_device(self, ptr, arr):
+        arr = np.ascontiguousarray(arr)
+        self._check(self._lib.sono_copy_to_device(self._ctx, C.c_void_p(ptr), F.ptr(arr), arr.nbytes))
+
+    def resample_cols_device(self, in_ptr, in_frames, bins, out_width, col0, ncols, out_ptr):
+        """Columns [col0, col0 + ncols) of resample's out_width-column result, device to device."""
+        self._check(self._lib.sono_resample_cols(self._ctx, C.c_void_p(in_ptr), int(in_frames), int(bins), int(out_width),
+                                                 int(col0), int(ncols), C.c_void_p(out_ptr), F.MEM_DEVICE))
+
+    def canvas_draw_device(self, cols_ptr, width, bins, sy, sh, dy, dh, height, background, out_ptr):
+        bg = None if background is None else np.ascontiguousarray(background, np.uint8).reshape(4)
+        self._check(self._lib.sono_canvas_draw(self._ctx, C.c_void_p(cols_ptr), int(width), int(bins), int(sy), int(sh), float(dy),
+                                               float(dh), int(height), None if bg is None else F.ptr(bg), C.c_void_p(out_ptr),
+                                               F.MEM_DEVICE))
+
     def pcm_to_device(self, raw, format_tag, bits, channels=1, channel=0):
         """Interleaved PCM bytes (host) -> float32 samples of one channel in device memory.  Returns
         (device pointer, frames); free it with device_free."""

@@ -601,3 +601,39 @@ def test_canvas_draw_edges():
     got = eng.canvas_draw(cols3, 0, 4096, 0.0, 64.0, 64, bg2)
     assert np.array_equal(got, oracle.canvas_draw(img3, 0, 4096, 0.0, 64.0, 64, bg2))
     eng.close()
+
+
+@pytest.mark.gpu
+def test_tile_cache_renders_views_without_recomputing():
+    """Tiles of a zoomed view come from the cached index plane and equal the same columns of the whole
+    canvas; colour map, frequency range and height changes hit the cache; a different hop misses."""
+    from spectrogram_amd.tiles import TileCache
+    x, sr = G.signal("bat"), G.sample_rate("bat")
+    buf = AudioBuffer(x, sr)
+    cm = G.colormap("default").tolist()
+    p = createSpectrogramPlugin(cm, height=300, frequencyMin=10, frequencyMax=120, fftSamples=512, noverlap=384, arith="exact")
+    width = 700
+    whole = p.renderCanvas(buf, width)
+    cache = TileCache()
+    tiles = [cache.tile("rec", p, buf, width, x0, min(256, width - x0)) for x0 in range(0, width, 256)]
+    assert np.array_equal(np.concatenate(tiles, axis=1), whole)
+    assert (cache.misses, cache.hits) == (1, 2)
+    # another colour map, band and height: same plane
+    q = createSpectrogramPlugin(G.colormap("rainbow").tolist(), height=200, frequencyMin=20, frequencyMax=90, fftSamples=512,
+                                noverlap=384, arith="exact")
+    assert np.array_equal(cache.tile("rec", q, buf, 333), q.renderCanvas(buf, 333))
+    assert (cache.misses, cache.hits) == (1, 3)
+    # another hop: a new plane; a tiny capacity evicts the old one
+    r = createSpectrogramPlugin(cm, height=64, fftSamples=512, noverlap=256, arith="exact")
+    small = TileCache(capacity_bytes=1)
+    a = small.tile("rec", p, buf, 100)
+    b = small.tile("rec", r, buf, 100)
+    assert small.misses == 2 and len(small._planes) == 1 and np.array_equal(b, r.renderCanvas(buf, 100))
+    assert np.array_equal(a, p.renderCanvas(buf, 100))
+    with pytest.raises(ValueError):
+        cache.tile("rec", p, buf, 100, 90, 20)
+    cache.drop("rec")
+    small.drop()
+    assert cache.used == 0 and small.used == 0
+    for s in (p, q, r):
+        s.destroy()

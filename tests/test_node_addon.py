@@ -55,3 +55,12 @@ def test_node_file_batch_on_gpu():
     p, res = run_node("test_batch.js")
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
     assert res["failures"] == 0 and res["checks"] >= 40
+
+
+@needs_node
+@pytest.mark.gpu
+def test_node_tile_cache_and_bridge_on_gpu():
+    """node/tiles.js + node/bridge.js: canvas tiles from the cached index plane, directly and over HTTP on 127.0.0.1."""
+    p, res = run_node("test_bridge.js")
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    assert res["failures"] == 0 and res["checks"] >= 20
