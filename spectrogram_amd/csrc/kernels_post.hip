@@ -51,13 +51,16 @@ int launch_resample(const uint8_t* in, uint64_t F, uint32_t bins, uint64_t W, ui
 
 // ------------------------------------------------------------------------------------------
 // LUT + vertical flip (+ row window), spectrogram.esm.js:366-380.  frames is [width][bins];
-// image row r holds bin bins-1-r.  A 64x64 tile goes through LDS so that both the byte reads
-// (along bins) and the pixel writes (along columns) are contiguous.
-// Tile: 256 columns (frames) x 64 image rows.  Every image row gets a 1-KiB run of pixels per
-// tile (one wavefront-wide 16-B-per-lane store), which keeps DRAM pages open on the write side -- the
-// image rows are tens of megabytes apart; the uint8 source is read 64 B per frame, but it is small
-// and usually still cache-resident.
-constexpr int kTileCols = 256, kTileRows = 64, kTileStride = kTileRows + 4;
+// image row r holds bin bins-1-r.  A tile of 256 columns (frames) x 64 image rows goes through LDS so
+// that both the byte reads (along bins) and the pixel writes (along columns) are contiguous: every
+// image row gets a 1-KiB run of pixels per tile (one wavefront-wide 16-B-per-lane store), which keeps
+// DRAM pages open on the write side -- the image rows are tens of megabytes apart.
+// The runs are shifted row by row so that each starts on a 64-byte boundary of the image: the row pitch
+// is rarely a multiple of 64 bytes, and a run that starts mid-sector leaves two partial sectors, which
+// cost the memory a read-modify-write each.  Row r of tile t covers columns [t0 + s_r, t0 + 256 + s_r),
+// s_r < 16 being the distance to the next boundary; the first tile also takes the s_r leading columns
+// and the last tile stops at the image edge.  The tile therefore holds 16 extra columns.
+constexpr int kTileCols = 256, kTileRows = 64, kTileStride = kTileRows + 4, kTileExtra = 16;
 
 // frames: [ncols][bins] uint8.  Image: `rows` rows of `img_width` pixels; this call fills columns
 // [col0, col0 + ncols).  Image row r holds bin bins-1-(row0+r).
@@ -65,11 +68,11 @@ __global__ __launch_bounds__(256) void colorize_kernel(const uint8_t* __restrict
                                                       uint32_t row0, uint32_t rows, const uint32_t* __restrict__ lut,
                                                       uint32_t* __restrict__ rgba, uint64_t img_width, uint64_t col0,
                                                       int aligned4) {
-  __shared__ __attribute__((aligned(16))) uint8_t tile[kTileCols * kTileStride];  // [column][bin - e_lo]
+  __shared__ __attribute__((aligned(16))) uint8_t tile[(kTileCols + kTileExtra) * kTileStride];  // [column][bin - e_lo]
   const uint64_t t0 = (uint64_t)blockIdx.x * kTileCols;
   const uint32_t r0 = blockIdx.y * kTileRows;               // first image row of the tile (relative to row0)
   const uint32_t nrows = min((uint32_t)kTileRows, rows - r0);
-  const uint32_t ncol = (uint32_t)min((uint64_t)kTileCols, ncols - t0);
+  const uint32_t ncol = (uint32_t)min((uint64_t)(kTileCols + kTileExtra), ncols - t0);  // columns held by the tile
   // image rows r0 .. r0+nrows-1 are bins e_hi-1 .. e_lo (descending); the tile stores bin e at [e - e_lo]
   const uint32_t e_hi = bins - (row0 + r0);
   const uint32_t e_lo = e_hi - nrows;
@@ -91,19 +94,31 @@ __global__ __launch_bounds__(256) void colorize_kernel(const uint8_t* __restrict
   const uint32_t q = tid & 63;
   for (uint32_t rr = tid >> 6; rr < nrows; rr += 4) {
     const uint32_t e = nrows - 1 - rr;  // bin offset in the tile
-    uint32_t px[4];
+    uint32_t* row = rgba + (uint64_t)(r0 + rr) * img_width + col0 + t0;  // pixel of the tile's column 0
+    // pixels to the next 64-byte boundary (the image base is at least 4-byte aligned)
+    const uint32_t s = (16u - (uint32_t)((reinterpret_cast<uintptr_t>(row) >> 2) & 15u)) & 15u;
+    const uint32_t hi = min(ncol, (uint32_t)kTileCols + s);  // this row's run is the tile's columns [s, hi)
+    const uint32_t c = s + 4 * q;
+    if (c < hi) {
+      uint32_t px[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const uint32_t idx = tile[(4 * q + j) * kTileStride + e];
-      px[j] = lut ? lut[idx] : (idx | (idx << 8) | (idx << 16) | 0xff000000u);
+      for (int j = 0; j < 4; ++j) {
+        const uint32_t idx = c + j < hi ? tile[(c + j) * kTileStride + e] : 0u;
+        px[j] = lut ? lut[idx] : (idx | (idx << 8) | (idx << 16) | 0xff000000u);
+      }
+      uint32_t* dst = row + c;
+      if (c + 3 < hi && ((reinterpret_cast<uintptr_t>(dst) & 15) == 0)) {
+        *reinterpret_cast<uint4*>(dst) = make_uint4(px[0], px[1], px[2], px[3]);
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (c + j < hi) dst[j] = px[j];
+      }
     }
-    uint32_t* dst = rgba + (uint64_t)(r0 + rr) * img_width + col0 + t0 + 4 * q;
-    if (4 * q + 3 < ncol && ((reinterpret_cast<uintptr_t>(dst) & 15) == 0)) {
-      *reinterpret_cast<uint4*>(dst) = make_uint4(px[0], px[1], px[2], px[3]);
-    } else {
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-        if (4 * q + j < ncol) dst[j] = px[j];
+    // the first tile also owns the columns before its first boundary
+    if (t0 == 0 && q < s && q < hi) {
+      const uint32_t idx = tile[q * kTileStride + e];
+      row[q] = lut ? lut[idx] : (idx | (idx << 8) | (idx << 16) | 0xff000000u);
     }
   }
 }
