@@ -382,7 +382,8 @@ int sono_stft_async(sono_ctx* c, const void* pcm, uint64_t L, void* out, uint64_
       if (r != SONO_OK) return fail(c, r, "kernel launch failed: %s", hipGetErrorString(hipGetLastError()));
       return SONO_OK;
     }
-    if ((fast_eligible(c) || q.mw_ok) && q.out_kind == SONO_OUT_RGBA8 && q.row_of_bin0 == (int32_t)q.bin_hi - 1) {
+    const bool exact = c->cfg.arith == SONO_ARITH_EXACT_F64;
+    if ((fast_eligible(c) || q.mw_ok || exact) && q.out_kind == SONO_OUT_RGBA8 && q.row_of_bin0 == (int32_t)q.bin_hi - 1) {
       // RGBA through the fast kernel: colour indices of a chunk of frames go to a context-owned
       // [frame][bin] buffer small enough to stay in the Infinity Cache, then a transposing LUT
       // kernel writes the chunk's image columns.
@@ -390,7 +391,7 @@ int sono_stft_async(sono_ctx* c, const void* pcm, uint64_t L, void* out, uint64_
       u.out_kind = SONO_OUT_U8_INDEX;
       u.out_bins = q.bin_hi - q.bin_lo;
       u.out_bin0 = q.bin_lo;
-      if (fast_u8_available(u) || mw_u8_available(u)) {
+      if (exact ? exact1024_available(u) : (fast_u8_available(u) || mw_u8_available(u))) {
         const uint64_t nb = u.out_bins;
         const uint64_t chunk = ((uint64_t)96 << 20) / nb / 64 * 64;   // frames per chunk (96 MiB of indices)
         int rc2 = ensure(c, &c->d_aux, &c->d_aux_bytes, (q.nframes < chunk ? q.nframes : chunk) * nb);
@@ -400,7 +401,10 @@ int sono_stft_async(sono_ctx* c, const void* pcm, uint64_t L, void* out, uint64_
           u.nframes = (q.nframes - f < chunk) ? q.nframes - f : chunk;
           u.col0 = 0;
           u.out = c->d_aux;
-          if (u.nframes < 16) {
+          if (exact) {
+            r = launch_stft_exact(u, c->stream);
+            if (r == 1) r = launch_stft_general(u, true, c->stream);
+          } else if (u.nframes < 16) {
             r = launch_stft_general(u, false, c->stream);
           } else {
             r = launch_stft_fast(u, c->stream);
@@ -417,7 +421,8 @@ int sono_stft_async(sono_ctx* c, const void* pcm, uint64_t L, void* out, uint64_
     }
     if (fast_eligible(c)) r = launch_stft_fast(q, c->stream);
     if (r == 1 && q.mw_ok) r = launch_stft_mw(q, c->stream);
-    if (r == 1) r = launch_stft_general(q, c->cfg.arith == SONO_ARITH_EXACT_F64, c->stream);
+    if (exact) r = launch_stft_exact(q, c->stream);
+    if (r == 1) r = launch_stft_general(q, exact, c->stream);
     if (r != SONO_OK) return fail(c, r, "kernel launch failed: %s", hipGetErrorString(hipGetLastError()));
     return SONO_OK;
   };

@@ -1,0 +1,234 @@
+// Exact-arithmetic STFT for 1024-point frames, in registers.
+//
+// Same operation sequence as the general kernel's double flavour -- the radix-2 decimation-in-time
+// network of spectrogramWorker.js:206-253 / spectrogram.esm.js:166-193 with per-stage twiddle tables,
+// double butterflies over float32 storage, no FMA contraction -- so the results are bit-identical to it
+// and to the JavaScript.  Only the schedule differs: a butterfly's inputs and factor are fixed by the
+// network, not by who computes it, so the ten stages are run as two in-register passes of five stages
+// with one transpose through LDS in between, instead of ten LDS round trips with workgroup barriers.
+//
+// One half-wavefront (32 lanes) per frame.  The working array A[0..1023] (bit-reversed input order):
+//   pass 1, stages T = 1..16 : lane l holds A[32l + r] in register r; the factor of a butterfly depends
+//                               on r only (tw[T-1 + (r mod T)]), wave-uniform, read as scalars;
+//   transpose                 : lane l holds A[32r + l] in register r;
+//   pass 2, stages T = 32..512: partner registers are T/32 apart; the factor tw[T-1 + 32*(r mod T/32) + l]
+//                               differs per lane and is read from a [31][32] double2 copy in LDS.
+// A[k] is then X[k] in natural order: lane l, register r < 16 holds bin 32r + l.
+//
+// Compile with -ffp-contract=off.
+#include <hip/hip_runtime.h>
+
+#include "sono_device.h"
+#include "sono_internal.h"
+
+namespace sono {
+namespace exact1024 {
+
+constexpr int kWaves = 8;           // wavefronts per workgroup: 16 frames per iteration
+constexpr int kPlane = 32 * 33;     // floats of one transpose buffer (row stride 33: conflict-free both ways)
+constexpr int kTwBytes = 31 * 32 * 16;
+constexpr int kWinBytes = 1024 * 4;
+constexpr int kLdsBytes = kTwBytes + kWinBytes + kWaves * 2 * kPlane * 4;
+
+__host__ __device__ constexpr int brev5(int v) {
+  return ((v & 1) << 4) | ((v & 2) << 2) | (v & 4) | ((v & 8) >> 2) | ((v & 16) >> 4);
+}
+
+// spectrogramWorker.js:233-252 / spectrogram.esm.js:181-191: t = w * A[M]; A[M] = A[k] - t; A[k] += t,
+// every product and sum a double, every store a float32.
+__device__ __forceinline__ void butterfly(float& rk, float& ik, float& rM, float& iM, double g, double s) {
+  const double oM = rM, lM = iM, ok = rk, lk = ik;
+  const double m = g * oM - s * lM;
+  const double y = g * lM + s * oM;
+  rM = (float)(ok - m);
+  iM = (float)(lk - y);
+  rk = (float)(ok + m);
+  ik = (float)(lk + y);
+}
+
+__device__ __forceinline__ void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <typename In>
+__device__ __forceinline__ float ld(const In* p, uint64_t i);
+template <>
+__device__ __forceinline__ float ld<float>(const float* p, uint64_t i) {
+  return p[i];
+}
+template <>
+__device__ __forceinline__ float ld<int16_t>(const int16_t* p, uint64_t i) {
+  return (float)p[i] * (1.0f / 32768.0f);
+}
+
+template <typename In>
+__global__ __launch_bounds__(kWaves * 64) void stft1024_exact_kernel(StftParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  double2* tw_lds = reinterpret_cast<double2*>(smem);                 // [31][32]: row t-1+j of stage T = 32t
+  float* win_lds = reinterpret_cast<float*>(smem + kTwBytes);          // window[j]
+  const double2* __restrict__ tw = reinterpret_cast<const double2*>(p.twiddles);
+  for (int i = threadIdx.x; i < 31 * 32; i += kWaves * 64) {
+    const int row = i >> 5, lane_p = i & 31;
+    const int t = 1 << (31 - __builtin_clz(row + 1)), j = row + 1 - t;
+    tw_lds[i] = tw[32 * t - 1 + 32 * j + lane_p];
+  }
+  for (int i = threadIdx.x; i < 1024; i += kWaves * 64) win_lds[i] = p.window[i];
+  __syncthreads();
+
+  const int lane = threadIdx.x & 63, l = lane & 31, h = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  float* plane = reinterpret_cast<float*>(smem + kTwBytes + kWinBytes) + (wave * 2 + h) * kPlane;
+  const In* __restrict__ x = reinterpret_cast<const In*>(p.pcm);
+  const int lb = brev5(l);
+  const double two_over_n = 2.0 / 1024.0;
+  const bool worker = p.scale_mode == SONO_SCALE_WORKER_LOG5;
+
+  for (uint64_t base = (uint64_t)blockIdx.x * (kWaves * 2); base < p.nframes; base += (uint64_t)gridDim.x * (kWaves * 2)) {
+    const uint64_t fi = base + wave * 2 + h;      // frame of this half-wavefront within the launch
+    const bool live = fi < p.nframes;
+    const uint64_t frame = p.frame0 + (live ? fi : p.nframes - 1);  // a spare half repeats the last frame and stores nothing
+    const uint64_t a = frame * p.hop;
+
+    // A[32l + r] = float32(x[j] * w[j]) with j = bitreverse10(32l + r) = 32*brev5(r) + brev5(l)
+    float re[32], im[32];
+#pragma unroll
+    for (int q = 0; q < 32; ++q) {
+      const int j = 32 * q + lb;
+      re[brev5(q)] = ld<In>(x, a + j) * win_lds[j];
+      im[brev5(q)] = 0.0f;
+    }
+    // stages T = 1, 2, 4, 8, 16
+#pragma unroll
+    for (int T = 1; T < 32; T <<= 1) {
+#pragma unroll
+      for (int z = 0; z < T; ++z) {
+        const double2 w = tw[T - 1 + z];  // wave-uniform
+#pragma unroll
+        for (int g = 0; g < 32; g += 2 * T) butterfly(re[g + z], im[g + z], re[g + z + T], im[g + z + T], w.x, w.y);
+      }
+    }
+    // transpose: lane l, register r  ->  lane r, register l (one plane after the other through one buffer)
+#pragma unroll
+    for (int r = 0; r < 32; ++r) plane[l * 33 + r] = re[r];
+    wave_sync();
+#pragma unroll
+    for (int r = 0; r < 32; ++r) re[r] = plane[r * 33 + l];
+    wave_sync();
+#pragma unroll
+    for (int r = 0; r < 32; ++r) plane[l * 33 + r] = im[r];
+    wave_sync();
+#pragma unroll
+    for (int r = 0; r < 32; ++r) im[r] = plane[r * 33 + l];
+    wave_sync();
+    // stages T = 32t, t = 1, 2, 4, 8, 16
+#pragma unroll
+    for (int t = 1; t < 32; t <<= 1) {
+#pragma unroll
+      for (int j = 0; j < t; ++j) {
+        const double2 w = tw_lds[(t - 1 + j) * 32 + l];
+#pragma unroll
+        for (int g = 0; g < 32; g += 2 * t) butterfly(re[g + j], im[g + j], re[g + j + t], im[g + j + t], w.x, w.y);
+      }
+    }
+
+    // bins 32r + l, r < 16.  The quantisers are long (double sqrt and log10), so the bins are parked in
+    // the transpose buffer and taken one at a time by a rolled loop instead of 16 inlined copies.
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      plane[r * 33 + l] = re[r];
+      plane[(16 + r) * 33 + l] = im[r];
+    }
+    wave_sync();
+    const uint64_t orow = (p.col0 + fi) * p.out_bins;
+    if (p.out_kind == SONO_OUT_FEATURES) {
+      // first bin of the band whose float32 magnitude exceeds all earlier ones (strict >)
+      float best_m = -1.0f, best_r = 0.0f, best_i = 0.0f;
+      int best_k = (int)p.bin_lo;
+#pragma unroll 1
+      for (int r = 0; r < 16; ++r) {
+        const int y = 32 * r + l;
+        const float fr = plane[r * 33 + l], fi2 = plane[(16 + r) * 33 + l];
+        const double e = fr, s = fi2;
+        const double mag = sqrt(e * e + s * s);
+        const float m = worker ? (float)mag : (float)(two_over_n * mag);
+        if (y >= (int)p.bin_lo && y < (int)p.bin_hi && m > best_m) {
+          best_m = m; best_k = y; best_r = fr; best_i = fi2;
+        }
+      }
+#pragma unroll
+      for (int msk = 1; msk < 32; msk <<= 1) {
+        const float om = __shfl_xor(best_m, msk, 64), orr = __shfl_xor(best_r, msk, 64), oi = __shfl_xor(best_i, msk, 64);
+        const int ok = __shfl_xor(best_k, msk, 64);
+        if (om > best_m || (om == best_m && ok < best_k)) { best_m = om; best_k = ok; best_r = orr; best_i = oi; }
+      }
+      if (l == 0 && live) {
+        sono_frame_feature ft;
+        ft.peak_bin = best_k;
+        ft.peak_idx = (uint8_t)(worker ? worker_index_exact(best_r, best_i)
+                                       : plugin_index_exact(plugin_mag_exact(best_r, best_i, two_over_n), p.gain_db, p.range_db));
+        ft.reserved[0] = ft.reserved[1] = ft.reserved[2] = 0;
+        reinterpret_cast<sono_frame_feature*>(p.out)[p.col0 + fi] = ft;
+      }
+    } else if (live) {
+#pragma unroll 1
+      for (int r = 0; r < 16; ++r) {
+        const int y = 32 * r + l;
+        if (y < (int)p.bin_lo || y >= (int)p.bin_hi) continue;
+        const float fr = plane[r * 33 + l], fi2 = plane[(16 + r) * 33 + l];
+        const uint64_t o = orow + (uint32_t)(y - (int)p.out_bin0);
+        if (p.out_kind == SONO_OUT_U8_INDEX) {
+          const uint32_t idx = worker ? worker_index_exact(fr, fi2)
+                                      : plugin_index_exact(plugin_mag_exact(fr, fi2, two_over_n), p.gain_db, p.range_db);
+          reinterpret_cast<uint8_t*>(p.out)[o] = (uint8_t)idx;
+        } else {
+          const double e = fr, s = fi2;
+          const double mag = sqrt(e * e + s * s);
+          const float m = worker ? (float)mag : (float)(two_over_n * mag);
+          float v = m;
+          if (p.out_kind == SONO_OUT_F32_DB) {
+            const double sv = ((double)m > 1e-12) ? (double)m : 1e-12;
+            v = (float)(20 * log10(sv));
+          }
+          reinterpret_cast<float*>(p.out)[o] = v;
+        }
+      }
+    }
+    wave_sync();  // the buffer is rewritten by the next frame's transpose
+  }
+}
+
+}  // namespace exact1024
+
+bool exact1024_available(const StftParams& p) {
+  return p.n == 1024 && p.twiddles && !p.fb_bin && p.nframes >= 16 &&
+         (p.out_kind == SONO_OUT_U8_INDEX || p.out_kind == SONO_OUT_F32_DB || p.out_kind == SONO_OUT_F32_MAG ||
+          p.out_kind == SONO_OUT_FEATURES);
+}
+
+// Returns 1 if this launch is not served here (the caller falls back to the general kernel).
+int launch_stft_exact(const StftParams& p, void* stream_v) {
+  using namespace exact1024;
+  if (!exact1024_available(p)) return 1;
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_v);
+  int dev = 0, cus = 256;
+  hipDeviceProp_t prop;
+  if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+    cus = prop.multiProcessorCount;
+  const uint64_t need = (p.nframes + kWaves * 2 - 1) / (kWaves * 2);
+  const uint32_t grid = (uint32_t)(need < (uint64_t)cus ? need : (uint64_t)cus);
+#define SONO_LAUNCH_X(In)                                                                                        \
+  do {                                                                                                           \
+    auto kern = stft1024_exact_kernel<In>;                                                                       \
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,     \
+                            kLdsBytes) != hipSuccess)                                                            \
+      return SONO_ERR_DEVICE;                                                                                    \
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kWaves * 64), kLdsBytes, stream, p);                               \
+  } while (0)
+  if (p.in_kind == SONO_IN_I16) SONO_LAUNCH_X(int16_t); else SONO_LAUNCH_X(float);
+#undef SONO_LAUNCH_X
+  return hipGetLastError() == hipSuccess ? SONO_OK : SONO_ERR_DEVICE;
+}
+
+}  // namespace sono

@@ -54,6 +54,10 @@ void build_fast_table_1024(std::vector<float>& t);
 // (returns 1 if it does not serve this size / layout).
 int launch_stft_mw(const StftParams& p, void* hip_stream);
 bool mw_u8_available(const StftParams& p);
+// kernels_exact.hip: the exact arithmetic for 1024-point frames, two in-register passes (returns 1 if it does not
+// serve this launch; results are bit-identical to launch_stft_general(p, true, ...)).
+int launch_stft_exact(const StftParams& p, void* hip_stream);
+bool exact1024_available(const StftParams& p);
 // kernels_post.hip
 int launch_resample(const uint8_t* in, uint64_t in_frames, uint32_t bins, uint64_t out_width, uint64_t col0, uint64_t ncols,
                     uint8_t* out, void* hip_stream);

@@ -637,3 +637,38 @@ def test_tile_cache_renders_views_without_recomputing():
     assert cache.used == 0 and small.used == 0
     for s in (p, q, r):
         s.destroy()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("hop,frames", [(256, 17), (100, 64), (512, 33)])
+def test_exact_register_kernel_outputs(hop, frames):
+    """1024-point frames in exact arithmetic run as two in-register passes; every output kind, an odd frame count
+    (a spare half-wavefront), a band, int16 input: bit-identical to the checker."""
+    rng = np.random.default_rng(hop)
+    L = 1024 + hop * frames                      # strict rule: `frames` frames; worker rule: frames + 1
+    x = (rng.standard_normal(L) * 0.05).astype(np.float32)
+    x[L // 4:L // 2] += (0.6 * np.sin(np.arange(L // 2 - L // 4) * 0.7)).astype(np.float32)
+    idx, mags, _, _ = oracle.plugin_get_frequencies(x, 1024, 1024 - hop, want_mags=True)
+    assert idx.shape[0] == frames
+    with plugin_engine(1024, hop, F.ARITH_EXACT_F64, out_kind=F.OUT_F32_MAG) as eng:
+        assert np.array_equal(eng.stft(x).view(np.uint32), mags.view(np.uint32))
+    with plugin_engine(1024, hop, F.ARITH_EXACT_F64, out_kind=F.OUT_F32_DB, bin_lo=24, bin_hi=400) as eng:
+        want = (20 * np.log10(np.maximum(mags[:, 24:400].astype(np.float64), 1e-12))).astype(np.float32)
+        got = eng.stft(x)
+        assert got.shape == want.shape and np.abs(got - want).max() <= 1e-4          # log10 of two libms
+    with plugin_engine(1024, hop, F.ARITH_EXACT_F64, bin_lo=100, bin_hi=356) as eng:
+        assert np.array_equal(eng.stft(x), idx[:, 100:356])
+    q = np.round(x * 32767).astype(np.int16)
+    xf = (q.astype(np.float32) / 32768).astype(np.float32)
+    with plugin_engine(1024, hop, F.ARITH_EXACT_F64, in_kind=F.IN_I16) as eng:
+        assert np.array_equal(eng.stft(q), oracle.plugin_get_frequencies(xf, 1024, 1024 - hop))
+    # worker rule: magnitudes, indices and per-frame peaks
+    wf = oracle.worker_frames(L, 1024, hop) if hasattr(oracle, "worker_frames") else frames + 1
+    wmag, widx = oracle.worker_magnitudes(x, 1024, hop, wf)
+    with worker_engine(1024, hop, F.ARITH_EXACT_F64, out_kind=F.OUT_U8_INDEX) as eng:
+        assert np.array_equal(eng.stft(x), widx)
+    with worker_engine(1024, hop, F.ARITH_EXACT_F64, out_kind=F.OUT_FEATURES, bin_lo=8, bin_hi=480) as eng:
+        ft = eng.stft(x)
+    pb = oracle.frame_peaks_f32(wmag, 8, 480)
+    assert np.array_equal(ft["peak_bin"], pb)
+    assert np.array_equal(ft["peak_idx"], widx[np.arange(wf), pb])
