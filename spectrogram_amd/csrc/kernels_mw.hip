@@ -78,6 +78,20 @@ __device__ __forceinline__ uint32_t put_index(float msq, const FastScale& fs, ui
   }
 }
 
+// Synchronises the threads of one transform.  A transform of up to 64 threads lives inside one wavefront, whose
+// LDS instructions execute in issue order: ordering them for the compiler is enough, and the wavefronts of the
+// workgroup stay independent.  Larger transforms span wavefronts and need the workgroup barrier (G == 1 there).
+template <int TN>
+__device__ __forceinline__ void group_sync() {
+  if constexpr (TN <= 64) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  } else {
+    __syncthreads();
+  }
+}
+
 // M > 0: hop == M * N/16, so frame B's sample t + (N/16)*a' is frame A's sample t + (N/16)*(a' + M) and one
 // run of 16 + M loads feeds both frames (75 %, 87.5 % and 93.75 % overlap are M = 4, 2, 1).  M == 0: any hop.
 template <int LOG2N, int G, int M, bool PLUGIN, typename In>
@@ -107,8 +121,8 @@ __global__ __launch_bounds__((1 << LOG2N) / 16 * G, 4) void stft_mw_kernel(StftP
 
   const uint64_t npairs = (p.nframes + 1) >> 1;
   for (uint64_t base = (uint64_t)blockIdx.x * G; base < npairs; base += (uint64_t)gridDim.x * G) {
-    // every group of the workgroup goes through every iteration (barriers); one without a pair of its
-    // own repeats the last pair and stores nothing
+    // every group of the workgroup goes through every iteration (the larger sizes meet at barriers); one
+    // without a pair of its own repeats the last pair and stores nothing
     const bool active = base + grp < npairs;
     const uint64_t pair = active ? base + grp : npairs - 1;
     uint64_t f0 = 2 * pair;
@@ -150,7 +164,7 @@ __global__ __launch_bounds__((1 << LOG2N) / 16 * G, 4) void stft_mw_kernel(StftP
       s_re[cellA + a] = re[a];
       s_im[cellA + a] = im[a];
     }
-    __syncthreads();
+    group_sync<TN>();
 #pragma unroll
     for (int b = 0; b < 16; ++b) {
       re[b] = s_re[cellB + 16 * b + (b >> 1)];
@@ -166,7 +180,7 @@ __global__ __launch_bounds__((1 << LOG2N) / 16 * G, 4) void stft_mw_kernel(StftP
       s_re[cellB + 16 * b + (b >> 1)] = re[b];
       s_im[cellB + 16 * b + (b >> 1)] = im[b];
     }
-    __syncthreads();
+    group_sync<TN>();
 #pragma unroll
     for (int s = 0; s < SETS; ++s) {
       const int w = t + TN * s;
@@ -185,7 +199,7 @@ __global__ __launch_bounds__((1 << LOG2N) / 16 * G, 4) void stft_mw_kernel(StftP
         s_im[cellC + 264 * c] = im[s * NC + c];
       }
     }
-    __syncthreads();
+    group_sync<TN>();
     // epilogue: thread handles the bin quads q = t, t + TN (N/8 quads per frame)
     const uint64_t row_a = (p.col0 + f0) * p.out_bins, row_b = row_a + p.out_bins;
 #pragma unroll
@@ -211,7 +225,7 @@ __global__ __launch_bounds__((1 << LOG2N) / 16 * G, 4) void stft_mw_kernel(StftP
         if (active) *reinterpret_cast<uint32_t*>(out + row_b + col) = wb;
       }
     }
-    __syncthreads();  // the planes are rewritten by the next pair
+    group_sync<TN>();  // the planes are rewritten by the next pair
   }
 }
 
