@@ -315,6 +315,19 @@ static uint32_t fast_mode_of(const sono_ctx* c) {
   return 2;
 }
 static bool fast_eligible(const sono_ctx* c) { return fast_mode_of(c) != 0; }
+// Largest deviation of the twiddle table from conjugate symmetry, |w[T-j] + conj(w[j])| over every stage of half
+// size T (StftParams::pair_exact).
+static double table_asymmetry(const sono_ctx* c) {
+  double worst = 0;
+  for (uint32_t T = 2; T < c->cfg.fft_n; T <<= 1)
+    for (uint32_t j = 1; j < T; j++) {
+      const double dr = c->h_cos[T - 1 + (T - j)] + c->h_cos[T - 1 + j];
+      const double di = c->h_sin[T - 1 + (T - j)] - c->h_sin[T - 1 + j];
+      const double d = std::sqrt(dr * dr + di * di);
+      if (d > worst) worst = d;
+    }
+  return worst;
+}
 // The 2048/4096-point kernel takes any twiddle table whose stages start with the factor (1, 0).
 static bool mw_eligible(const sono_ctx* c) {
   if (c->cfg.arith != SONO_ARITH_FAST_F32 || (c->cfg.fft_n != 512 && c->cfg.fft_n != 2048 && c->cfg.fft_n != 4096) || c->d_fb_bin)
@@ -354,6 +367,7 @@ int sono_stft_async(sono_ctx* c, const void* pcm, uint64_t L, void* out, uint64_
   p.fast_table = c->d_fast;
   p.fast_mode = fast_mode_of(c);
   p.mw_ok = mw_eligible(c) ? 1u : 0u;
+  p.pair_exact = table_asymmetry(c) <= 5e-7 ? 1u : 0u;
   p.fb_bin = c->d_fb_bin;
   p.fb_w0 = c->d_fb_w;
   p.fb_w1 = c->d_fb_w ? c->d_fb_w + n / 2 : nullptr;

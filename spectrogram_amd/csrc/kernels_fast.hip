@@ -624,6 +624,7 @@ int launch_stft_fast(const StftParams& p, void* stream_v) {
     if (!fast_rgba_available(p) || !p.tile_scratch) return 1;
   } else if (flt) {
     if (!fast_float_available(p)) return 1;
+    if (p.fast_mode == 2 && !p.pair_exact) return 1;  // two frames per transform: see StftParams::pair_exact
   } else if (feat) {
     if (!fast_features_available(p)) return 1;
   } else {

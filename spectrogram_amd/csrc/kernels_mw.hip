@@ -94,9 +94,16 @@ __device__ __forceinline__ void group_sync() {
 
 // M > 0: hop == M * N/16, so frame B's sample t + (N/16)*a' is frame A's sample t + (N/16)*(a' + M) and one
 // run of 16 + M loads feeds both frames (75 %, 87.5 % and 93.75 % overlap are M = 4, 2, 1).  M == 0: any hop.
-template <int LOG2N, int G, int M, bool PLUGIN, typename In>
+// OUT: kOutU8 [frame][bin] colour indices; kOutDb / kOutMag [frame][bin] float32 20*log10(m) / m; kOutFeatures
+// [frame] spectral peak (strict-> first-wins argmax of |X|^2 over the band and that bin's colour index).
+constexpr int kOutU8 = 0, kOutFeatures = 2, kOutDb = 3, kOutMag = 4;
+template <int LOG2N, int G, int M, bool PLUGIN, typename In, int OUT>
 __global__ __launch_bounds__((1 << LOG2N) / 16 * G, 4) void stft_mw_kernel(StftParams p, FastScale fs) {
   constexpr int N = 1 << LOG2N, TN = N / 16, CB = LOG2N - 8, NC = 1 << CB, SETS = 16 / NC;
+  constexpr bool FEAT = OUT == kOutFeatures, FLT = OUT == kOutDb || OUT == kOutMag;
+  constexpr int kWavesPerGroup = TN > 64 ? TN / 64 : 1;
+  __shared__ float s_best[FEAT ? G * kWavesPerGroup * 2 : 1];   // FEAT, transforms wider than a wavefront:
+  __shared__ int s_bestk[FEAT ? G * kWavesPerGroup * 2 : 1];    // per-wavefront peaks of the two frames
   static_assert(CB >= 1 && CB <= 4, "512 to 4096 points");
   constexpr int kPlane = N + N / 32;
   __shared__ float s_re_all[G][kPlane], s_im_all[G][kPlane];
@@ -202,11 +209,15 @@ __global__ __launch_bounds__((1 << LOG2N) / 16 * G, 4) void stft_mw_kernel(StftP
     group_sync<TN>();
     // epilogue: thread handles the bin quads q = t, t + TN (N/8 quads per frame)
     const uint64_t row_a = (p.col0 + f0) * p.out_bins, row_b = row_a + p.out_bins;
+    const float mag_scale = PLUGIN ? 1.0f / (float)N : 0.5f;  // the pair separation leaves 2*X; plugin: 2/N * |X|
+    float best_a = -1.0f, best_b = -1.0f;                     // FEAT: this thread's largest |X|^2 so far and its bin
+    int kbest_a = (int)p.bin_lo, kbest_b = (int)p.bin_lo;
 #pragma unroll
     for (int m = 0; m < (N / 8) / TN; ++m) {
       const int k = 4 * (t + TN * m);
       if (k >= (int)p.bin_lo && k < (int)p.bin_hi) {
         uint32_t wa = 0, wb = 0;
+        float fa[4] = {0, 0, 0, 0}, fb[4] = {0, 0, 0, 0};
         const int cellZ = k + (k >> 5);  // + B (k is a multiple of 4)
 #define SONO_BIN(B)                                                            \
   {                                                                            \
@@ -215,14 +226,72 @@ __global__ __launch_bounds__((1 << LOG2N) / 16 * G, 4) void stft_mw_kernel(StftP
     const float pr = s_re[pad(km)], pi = s_im[pad(km)];                        \
     const float ar = zr + pr, ai = zi - pi;                                    \
     const float br = zi + pi, bi = pr - zr;                                    \
-    wa = put_index<PLUGIN, B>(__builtin_fmaf(ar, ar, ai * ai), fs, wa);        \
-    wb = put_index<PLUGIN, B>(__builtin_fmaf(br, br, bi * bi), fs, wb);        \
+    const float ma = __builtin_fmaf(ar, ar, ai * ai);                          \
+    const float mb = __builtin_fmaf(br, br, bi * bi);                          \
+    if constexpr (FEAT) { /* a thread visits its bins in ascending order */    \
+      if (ma > best_a) { best_a = ma; kbest_a = k + B; }                       \
+      if (mb > best_b) { best_b = mb; kbest_b = k + B; }                       \
+    } else if constexpr (FLT) {                                                \
+      fa[B] = OUT == kOutDb ? fast_db(ma, fs) : __builtin_sqrtf(ma) * mag_scale; \
+      fb[B] = OUT == kOutDb ? fast_db(mb, fs) : __builtin_sqrtf(mb) * mag_scale; \
+    } else {                                                                   \
+      wa = put_index<PLUGIN, B>(ma, fs, wa);                                   \
+      wb = put_index<PLUGIN, B>(mb, fs, wb);                                   \
+    }                                                                          \
   }
         SONO_BIN(0) SONO_BIN(1) SONO_BIN(2) SONO_BIN(3)
 #undef SONO_BIN
         const uint32_t col = k - p.out_bin0;
-        if (st_a) *reinterpret_cast<uint32_t*>(out + row_a + col) = wa;
-        if (active) *reinterpret_cast<uint32_t*>(out + row_b + col) = wb;
+        if constexpr (FLT) {
+          float* o = reinterpret_cast<float*>(p.out) + col;
+          if (st_a) *reinterpret_cast<float4*>(o + row_a) = make_float4(fa[0], fa[1], fa[2], fa[3]);
+          if (active) *reinterpret_cast<float4*>(o + row_b) = make_float4(fb[0], fb[1], fb[2], fb[3]);
+        } else if constexpr (!FEAT) {
+          if (st_a) *reinterpret_cast<uint32_t*>(out + row_a + col) = wa;
+          if (active) *reinterpret_cast<uint32_t*>(out + row_b + col) = wb;
+        }
+      }
+    }
+    if constexpr (FEAT) {
+      // larger |X|^2 wins, equal values go to the lower bin: first across the lanes of the transform's wavefront
+      // (or its 32-lane half at 512 points), then across its wavefronts through LDS
+      auto take = [](float& bm, int& bk, float om, int ok) {
+        if (om > bm || (om == bm && ok < bk)) { bm = om; bk = ok; }
+      };
+#pragma unroll
+      for (int msk = 1; msk < (TN < 64 ? TN : 64); msk <<= 1) {
+        take(best_a, kbest_a, __shfl_xor(best_a, msk, 64), __shfl_xor(kbest_a, msk, 64));
+        take(best_b, kbest_b, __shfl_xor(best_b, msk, 64), __shfl_xor(kbest_b, msk, 64));
+      }
+      if constexpr (kWavesPerGroup > 1) {
+        const int wv = t >> 6;
+        if ((t & 63) == 0) {
+          s_best[(grp * kWavesPerGroup + wv) * 2] = best_a;     s_bestk[(grp * kWavesPerGroup + wv) * 2] = kbest_a;
+          s_best[(grp * kWavesPerGroup + wv) * 2 + 1] = best_b; s_bestk[(grp * kWavesPerGroup + wv) * 2 + 1] = kbest_b;
+        }
+        __syncthreads();
+        if (t == 0) {
+#pragma unroll
+          for (int v = 1; v < kWavesPerGroup; ++v) {
+            take(best_a, kbest_a, s_best[(grp * kWavesPerGroup + v) * 2], s_bestk[(grp * kWavesPerGroup + v) * 2]);
+            take(best_b, kbest_b, s_best[(grp * kWavesPerGroup + v) * 2 + 1], s_bestk[(grp * kWavesPerGroup + v) * 2 + 1]);
+          }
+        }
+      }
+      if (t == 0) {
+        sono_frame_feature* ft = reinterpret_cast<sono_frame_feature*>(p.out) + (p.col0 + f0);
+        if (st_a) {
+          sono_frame_feature r{};
+          r.peak_bin = kbest_a;
+          r.peak_idx = (uint8_t)put_index<PLUGIN, 0>(best_a, fs, 0);
+          ft[0] = r;
+        }
+        if (active) {
+          sono_frame_feature r{};
+          r.peak_bin = kbest_b;
+          r.peak_idx = (uint8_t)put_index<PLUGIN, 0>(best_b, fs, 0);
+          ft[1] = r;
+        }
       }
     }
     group_sync<TN>();  // the planes are rewritten by the next pair
@@ -240,8 +309,18 @@ bool mw_u8_available(const StftParams& p) {
 
 int launch_stft_mw(const StftParams& p, void* stream_v) {
   using namespace mw;
-  if (p.out_kind != SONO_OUT_U8_INDEX || !mw_u8_available(p)) return 1;
-  if (reinterpret_cast<uintptr_t>(p.out) & 3) return 1;
+  const bool u8 = p.out_kind == SONO_OUT_U8_INDEX, feat = p.out_kind == SONO_OUT_FEATURES;
+  const bool flt = p.out_kind == SONO_OUT_F32_DB || p.out_kind == SONO_OUT_F32_MAG;
+  if (!(u8 || feat || flt)) return 1;
+  if (flt && !p.pair_exact) return 1;  // two frames per transform: see StftParams::pair_exact
+  if (feat) {  // features do not use the output row layout
+    if ((p.n != 512 && p.n != 2048 && p.n != 4096) || !p.mw_ok || !p.twiddles || (p.bin_lo & 3) || (p.bin_hi & 3) ||
+        p.bin_lo >= p.bin_hi || p.nframes < 2)
+      return 1;
+  } else if (!mw_u8_available(p)) {
+    return 1;
+  }
+  if (reinterpret_cast<uintptr_t>(p.out) & (flt ? 15 : 3)) return 1;
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_v);
   FastScale fs = make_fast_scale(p.scale_mode, p.n, p.gain_db, p.range_db);
   fs.b -= 2.0f * fs.a;  // the pair separation leaves 2*X
@@ -257,13 +336,17 @@ int launch_stft_mw(const StftParams& p, void* stream_v) {
   const uint32_t grid = (uint32_t)(need < cap ? need : cap);
   const bool plugin = p.scale_mode == SONO_SCALE_PLUGIN_DB;
   const uint32_t tn = p.n / 16;
-  const int m = (p.hop % tn == 0 && (p.hop / tn == 1 || p.hop / tn == 2 || p.hop / tn == 4)) ? (int)(p.hop / tn) : 0;
-#define SONO_MW(L2, GR, MM, PL, In) \
-  hipLaunchKernelGGL((stft_mw_kernel<L2, GR, MM, PL, In>), dim3(grid), dim3((1 << L2) / 16 * GR), 0, stream, p, fs)
-#define SONO_MW_M(L2, GR, PL, In)                                                                \
-  do {                                                                                           \
-    if (m == 1) SONO_MW(L2, GR, 1, PL, In); else if (m == 2) SONO_MW(L2, GR, 2, PL, In);          \
-    else if (m == 4) SONO_MW(L2, GR, 4, PL, In); else SONO_MW(L2, GR, 0, PL, In);                 \
+  // shared sample loads (hop a small multiple of N/16) exist for the colour-index output only
+  const int m = (u8 && p.hop % tn == 0 && (p.hop / tn == 1 || p.hop / tn == 2 || p.hop / tn == 4)) ? (int)(p.hop / tn) : 0;
+#define SONO_MW(L2, GR, MM, PL, In, O) \
+  hipLaunchKernelGGL((stft_mw_kernel<L2, GR, MM, PL, In, O>), dim3(grid), dim3((1 << L2) / 16 * GR), 0, stream, p, fs)
+#define SONO_MW_M(L2, GR, PL, In)                                                                          \
+  do {                                                                                                     \
+    if (feat) SONO_MW(L2, GR, 0, PL, In, kOutFeatures);                                                    \
+    else if (p.out_kind == SONO_OUT_F32_DB) SONO_MW(L2, GR, 0, PL, In, kOutDb);                            \
+    else if (p.out_kind == SONO_OUT_F32_MAG) SONO_MW(L2, GR, 0, PL, In, kOutMag);                          \
+    else if (m == 1) SONO_MW(L2, GR, 1, PL, In, kOutU8); else if (m == 2) SONO_MW(L2, GR, 2, PL, In, kOutU8); \
+    else if (m == 4) SONO_MW(L2, GR, 4, PL, In, kOutU8); else SONO_MW(L2, GR, 0, PL, In, kOutU8);          \
   } while (0)
 #define SONO_MW_IN(L2, GR, PL)                                                                   \
   do {                                                                                           \

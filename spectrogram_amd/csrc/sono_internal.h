@@ -37,6 +37,10 @@ struct StftParams {
   const void* fast_table; // device: per-size twiddle matrix of the fast kernels, or nullptr
   uint32_t fast_mode;     // 0: no fast kernel; 1: exact roots of unity (fast_table); 2: the per-stage table `twiddles`
   uint32_t mw_ok;         // the twiddle table starts every stage with (1, 0): the 2048/4096-point kernel may run
+  uint32_t pair_exact;    // the table is conjugate-symmetric to float32 accuracy (w[T-j] == -conj(w[j]) in every stage), so
+                          // transforming two real frames as one complex frame separates them to float32 accuracy; the
+                          // plugin's recurrence factors are not (1e-5 off at 1024 points, 3e-5 at 4096), which is harmless
+                          // for colour indices and peaks but not for float32 outputs held to 0.01 dB
   const int32_t* fb_bin;  // device: non-linear frequency scale, first tap of output bin i (n/2 entries), or nullptr = linear
   const double* fb_w0;    // device: weight of bin fb_bin[i]
   const double* fb_w1;    // device: weight of bin fb_bin[i] + 1

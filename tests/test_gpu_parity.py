@@ -672,3 +672,61 @@ def test_exact_register_kernel_outputs(hop, frames):
     pb = oracle.frame_peaks_f32(wmag, 8, 480)
     assert np.array_equal(ft["peak_bin"], pb)
     assert np.array_equal(ft["peak_idx"], widx[np.arange(wf), pb])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [512, 2048, 4096])
+def test_float_and_feature_outputs_at_other_sizes(n):
+    """512 / 2048 / 4096 points in float32 (the multi-pass register kernel): dB within 0.01 dB over the displayed
+    range, magnitudes to float32 accuracy, per-frame peaks equal to the checker's unless two bins nearly tie."""
+    x = G.signal("bat")
+    hop = n // 4
+    idx, mags, _, _ = oracle.plugin_get_frequencies(x, n, n - hop, want_mags=True)
+    frames = idx.shape[0]
+    with plugin_engine(n, hop, F.ARITH_FAST_F32, out_kind=F.OUT_F32_MAG) as eng:
+        m = eng.stft(x)
+    assert m.shape == mags.shape
+    assert np.abs(m - mags).max() <= 2e-5 * mags.max()            # recurrence twiddles, float32 butterflies
+    with plugin_engine(n, hop, F.ARITH_FAST_F32, out_kind=F.OUT_F32_DB, bin_lo=8, bin_hi=n // 2 - 8) as eng:
+        db = eng.stft(x)
+    ref_db = 20 * np.log10(np.maximum(mags[:, 8:n // 2 - 8].astype(np.float64), 1e-12))
+    # above the display floor (-gainDB - rangeDB) and within 90 dB of the frame's peak (float32 round-off sits
+    # about 140 dB below the peak).  The plugin's recurrence factors are not conjugate-symmetric, so float32
+    # outputs never come from a kernel that transforms two frames at once (that would cost up to 0.03 dB here).
+    below_peak = ref_db.max(axis=1, keepdims=True) - ref_db
+    assert db.shape == ref_db.shape
+    assert np.abs(db - ref_db)[(ref_db >= -100.0) & (below_peak <= 90.0)].max() <= 0.01
+    # worker path (exact roots of unity): the two-frames-per-transform kernel serves float32 outputs too
+    wfr = (len(x) - n) // hop + 1
+    wm, _ = oracle.worker_magnitudes(x, n, hop, wfr)
+    with worker_engine(n, hop, F.ARITH_FAST_F32, out_kind=F.OUT_F32_DB) as eng:
+        wdb = eng.stft(x)
+    with worker_engine(n, hop, F.ARITH_FAST_F32, out_kind=F.OUT_F32_MAG, bin_lo=4, bin_hi=n // 4) as eng:
+        wmag = eng.stft(x)
+    assert wdb.shape == wm.shape and wmag.shape == (wfr, n // 4 - 4)
+    shown = wm >= 1.0                                             # the worker's display range starts at |X| = 1
+    assert np.abs(wdb[shown] - 20 * np.log10(wm[shown].astype(np.float64))).max() <= 0.01
+    assert np.abs(wmag - wm[:, 4:n // 4]).max() <= 2e-6 * wm.max()
+    for lo, hi in ((0, 0), (16, n // 4)):
+        with plugin_engine(n, hop, F.ARITH_FAST_F32, out_kind=F.OUT_FEATURES, bin_lo=lo, bin_hi=hi) as eng:
+            ft = eng.stft(x)
+        ref = oracle.frame_peaks_f32(mags, lo, hi or n // 2)
+        assert len(ft) == frames
+        diff = np.nonzero(ft["peak_bin"] != ref)[0]
+        for f in diff:
+            a, b = mags[f, ref[f]], mags[f, ft["peak_bin"][f]]
+            assert abs(a - b) <= 2e-5 * a
+        assert len(diff) <= 2
+        d = cyc_diff(ft["peak_idx"], idx[np.arange(frames), ft["peak_bin"]])
+        assert d.max() <= 1
+    # worker rule with int16 samples and an odd frame count
+    wf = (len(x) - n) // hop + 1
+    wf -= 1 - wf % 2                                              # an odd number of frames (i + N <= L)
+    q = np.round(x * 32767).astype(np.int16)[:n + hop * (wf - 1)]
+    xf = (q.astype(np.float32) / 32768).astype(np.float32)
+    wm, wi = oracle.worker_magnitudes(xf, n, hop, wf)
+    with worker_engine(n, hop, F.ARITH_FAST_F32, out_kind=F.OUT_FEATURES, in_kind=F.IN_I16) as eng:
+        ft = eng.stft(q)
+    ref = oracle.frame_peaks_f32(wm)
+    assert len(ft) == wf and (ft["peak_bin"] != ref).sum() <= 1
+    assert np.abs(ft["peak_idx"].astype(np.int16) - wi[np.arange(wf), ft["peak_bin"]]).max() <= 1
