@@ -20,5 +20,10 @@ run worker_u8_512 600 5 u8 512 128 worker
 run plugin_u8_2048 600 5 u8 2048 512 plugin
 run plugin_u8_4096 600 5 u8 4096 256 plugin
 run plugin_rgba_4096_crop 60 5 rgba 4096 256 plugin 160 1280
+run plugin_features_512 600 5 feat 512 128 plugin
+run plugin_features_4096 600 5 feat 4096 1024 plugin
+run worker_rgba_512 600 5 rgba 512 128 worker
+run plugin_u8_1024_exact 120 3 u8 1024 256 plugin 0 0 exact
+run worker_rgba_1024_exact 120 3 rgba 1024 256 worker 0 0 exact
 rm -f "$OUT"/*.log
 ls "$OUT"

@@ -1,5 +1,5 @@
 // Native benchmark / profiling host for libsonospec.so: no Python, no PyTorch, just the C ABI.
-//   sono_bench [seconds=600] [steps=5] [out=u8|rgba|feat] [fft=1024] [hop=256] [path=worker|plugin] [bin_lo bin_hi]
+//   sono_bench [seconds=600] [steps=5] [out=u8|rgba|feat] [fft=1024] [hop=256] [path=worker|plugin] [bin_lo bin_hi (0 0 = all)] [arith=fast|exact]
 // Generates a seeded synthetic recording on the host, copies it to the GPU once, runs the worker-path
 // transform `steps` times on device-resident buffers and prints Msamples/s from HIP-event timing.
 #include <cmath>
@@ -37,9 +37,9 @@ int main(int argc, char** argv) {
   cfg.scale_mode = plugin ? SONO_SCALE_PLUGIN_DB : SONO_SCALE_WORKER_LOG5;
   cfg.frame_rule = plugin ? SONO_FRAMES_PLUGIN_STRICT : SONO_FRAMES_WORKER_COMPAT;
   cfg.twiddle_mode = plugin ? SONO_TW_PLUGIN_RECURRENCE : SONO_TW_ACCURATE;
-  cfg.arith = SONO_ARITH_FAST_F32;
+  cfg.arith = (argc > 9 && !strcmp(argv[9], "exact")) ? SONO_ARITH_EXACT_F64 : SONO_ARITH_FAST_F32;
   cfg.out_kind = rgba ? SONO_OUT_RGBA8 : feat ? SONO_OUT_FEATURES : SONO_OUT_U8_INDEX;
-  if (argc > 8) {
+  if (argc > 8 && atoi(argv[8]) > 0) {
     cfg.bin_lo = (uint32_t)atoi(argv[7]);
     cfg.bin_hi = (uint32_t)atoi(argv[8]);
   }
