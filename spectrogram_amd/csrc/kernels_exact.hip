@@ -172,7 +172,7 @@ __global__ __launch_bounds__(kWaves * 64) void stft1024_exact_kernel(StftParams 
         reinterpret_cast<sono_frame_feature*>(p.out)[p.col0 + fi] = ft;
       }
     } else if (live) {
-#pragma unroll 1
+#pragma unroll 4
       for (int r = 0; r < 16; ++r) {
         const int y = 32 * r + l;
         if (y < (int)p.bin_lo || y >= (int)p.bin_hi) continue;
