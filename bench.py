@@ -134,7 +134,8 @@ def main():
         else:                     # spectrogram.esm.js semantics (hann, recurrence twiddles, gain 20 / range 80)
             cfg = dict(window_id=E.window_id("hann"), scale_mode=F.SCALE_PLUGIN_DB, frame_rule=F.FRAMES_PLUGIN_STRICT,
                        twiddle_mode=F.TW_PLUGIN_RECURRENCE, gain_db=20.0, range_db=80.0)
-        eng = E.Engine(fft_n=fft_n, hop=hop, arith=F.ARITH_FAST_F32, out_kind=out_kind, device=local_rank, **cfg, **kw)
+        arith = F.ARITH_EXACT_F64 if kw.pop("exact", False) else F.ARITH_FAST_F32
+        eng = E.Engine(fft_n=fft_n, hop=hop, arith=arith, out_kind=out_kind, device=local_rank, **cfg, **kw)
         eng.set_stream(torch.cuda.current_stream().cuda_stream)
         return eng
 
@@ -225,9 +226,13 @@ def main():
             "u8_plugin_getFrequencies_1024": dict(out="u8", path="plugin"),
             "features_plugin_1024": dict(out="features", path="plugin"),
             "u8_worker_512_hop128": dict(out="u8", fft_n=512, hop=128),
+            "rgba_worker_512_hop128": dict(out="rgba", fft_n=512, hop=128),      # the page's default FFT size (main.js:886-889)
+            "features_plugin_512_hop128": dict(out="features", path="plugin", fft_n=512, hop=128),
             "u8_plugin_2048_hop512": dict(out="u8", path="plugin", fft_n=2048, hop=512),
             "rgba_plugin_4096_hop256_bins160-1280_60s": dict(out="rgba", path="plugin", fft_n=4096, hop=256, bin_lo=160,
                                                             bin_hi=1280, samples=c4),
+            # bit-identical arithmetic (double butterflies over float32 storage), 60 s of the recording
+            "rgba_worker_1024_exact_60s": dict(out="rgba", exact=True, samples=c4),
         }
         result["variants"] = {}
         for name, sp in specs.items():
