@@ -13,11 +13,12 @@ namespace sono {
 // Worker pixel value, spectrogramWorker.js:71-78.
 __device__ __forceinline__ uint32_t worker_index_exact(float re, float im) {
   const double magSq = (double)re * (double)re + (double)im * (double)im;
+  // sqrt and log10 are the long part: magnitudes up to 1 clamp to 0 and magnitudes safely above 1e5 clamp to 1
+  // whatever the last bits of log10 are; sqrt is monotone and exact at 1, so the test can be made on the square
+  // (a NaN takes the general route and ends as 0 like the reference's failed comparisons)
+  if (magSq <= 1.0) return 0;
+  if (magSq > 1.00002e10) return 255;
   const double mag = sqrt(magSq);
-  // log10 is the long part: magnitudes up to 1 clamp to 0 and magnitudes safely above 1e5 clamp to 1 whatever
-  // its last bits are (a NaN takes the general route and ends as 0 like the reference's failed comparisons)
-  if (mag <= 1.0) return 0;
-  if (mag > 100000.5) return 255;
   double val = (mag > 1e-12) ? log10(mag) / 5 : -2.4;
   val = val < 0 ? 0 : (val > 1 ? 1 : val);
   return (uint32_t)floor(val * 255);
