@@ -201,9 +201,9 @@ sono_ctx* sono_create(int device, const sono_config* cfg) {
     sono_destroy(c);
     return nullptr;
   }
-  if (cfg->arith == SONO_ARITH_FAST_F32 && cfg->twiddle_mode == SONO_TW_ACCURATE && n == 1024) {
+  if (cfg->arith == SONO_ARITH_FAST_F32 && cfg->twiddle_mode == SONO_TW_ACCURATE && (n == 1024 || n == 512)) {
     std::vector<float> t;
-    build_fast_table_1024(t);
+    if (n == 1024) build_fast_table_1024(t); else build_fast_table_512(t);
     if ((e = hipMalloc(&c->d_fast, sizeof(float) * t.size())) != hipSuccess) return bail("hipMalloc(fast table)", e);
     if ((e = hipMemcpy(c->d_fast, t.data(), sizeof(float) * t.size(), hipMemcpyHostToDevice)) != hipSuccess)
       return bail("hipMemcpy(fast table)", e);
@@ -307,8 +307,9 @@ static uint64_t in_bytes(const sono_ctx* c, uint64_t L) { return L * (c->cfg.in_
 
 // Which flavour of the fast 1024-point kernel serves this context (StftParams::fast_mode).
 static uint32_t fast_mode_of(const sono_ctx* c) {
-  if (c->cfg.arith != SONO_ARITH_FAST_F32 || c->cfg.fft_n != 1024 || c->d_fb_bin) return 0;
+  if (c->cfg.arith != SONO_ARITH_FAST_F32 || (c->cfg.fft_n != 1024 && c->cfg.fft_n != 512) || c->d_fb_bin) return 0;
   if (c->cfg.twiddle_mode == SONO_TW_ACCURATE && !c->host_twiddles) return c->d_fast ? 1 : 0;
+  if (c->cfg.fft_n != 1024) return 0;  // table twiddles: the 1024-point kernel only
   // table twiddles: the kernel folds the first butterfly of every stage, so that factor must be 1
   for (uint32_t T = 1; T < c->cfg.fft_n; T <<= 1)
     if (c->h_cos[T - 1] != 1.0 || c->h_sin[T - 1] != 0.0) return 0;
@@ -422,6 +423,7 @@ int sono_stft_async(sono_ctx* c, const void* pcm, uint64_t L, void* out, uint64_
             r = launch_stft_general(u, false, c->stream);
           } else {
             r = launch_stft_fast(u, c->stream);
+            if (r == 1) r = launch_stft_fast512(u, c->stream);
             if (r == 1) r = launch_stft_mw(u, c->stream);
             if (r == 1) r = launch_stft_general(u, false, c->stream);
           }
@@ -434,6 +436,7 @@ int sono_stft_async(sono_ctx* c, const void* pcm, uint64_t L, void* out, uint64_
       }
     }
     if (fast_eligible(c)) r = launch_stft_fast(q, c->stream);
+    if (r == 1 && fast_eligible(c)) r = launch_stft_fast512(q, c->stream);
     if (r == 1 && q.mw_ok) r = launch_stft_mw(q, c->stream);
     if (exact) r = launch_stft_exact(q, c->stream);
     if (r == 1) r = launch_stft_general(q, exact, c->stream);

@@ -1,0 +1,351 @@
+// Float32 STFT kernel for 512-point frames with exact roots of unity (the worker path at the page's default FFT
+// size, main.js:886-889; spectrogramWorker.js:38-99,206-253).  Compile with -ffp-contract=fast.
+//
+// Same machine mapping as the 1024-point kernel, with two transforms per half-wavefront:
+//   * a half-wavefront (32 lanes) transforms FOUR real frames as two complex 512-point frames A and B
+//     (z = x0 + i*x1); lane l holds samples 32a + l, a = 0..15, of A in registers 0..15 and of B in 16..31;
+//   * 512 = 16 x 32: the first pass is a 16-point transform in each register half (the first four stages of the
+//     32-point radix-2 network), then the twiddle W_512^(l*k1), then the same 32 x 32 transpose through LDS as the
+//     1024-point kernel: lane 16g + k1 now holds Y_l[k1] of transform g for l = 0..31, and the second pass is one
+//     32-point transform per lane: register k2 = Z_g[k1 + 16*k2];
+//   * epilogue in two halves of 128 bins, both transforms at once: registers 8P..8P+7 are Z[k], 128P <= k < 128P+128,
+//     registers 24-8P..31-8P their partners Z[512 - k]; both go through LDS in ascending k so that a lane reads
+//     four consecutive bins of both as 16-byte pieces, separates the two frames (X0 = (Z[k] + conj Z[N-k])/2,
+//     X1 = (Z[k] - conj Z[N-k])/(2i)) and fuses |X|^2 -> log2 -> quantiser -> packed uint8.
+//   * HOP32 > 0: hop == 32*HOP32, so the four frames of a half-wavefront are one run of 16 + 3*HOP32 loads.
+// Outputs: [frame][bin] colour indices, or per-frame spectral peaks.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <vector>
+
+#include "sono_device.h"
+#include "sono_internal.h"
+
+namespace sono {
+namespace fast512 {
+
+constexpr int kWaves = 16;                          // wavefronts per workgroup (one workgroup per CU): 128 frames per iteration
+constexpr int kPlaneStride = 36;                    // floats per transpose row (rows 16-B aligned, b128 reads conflict-free)
+constexpr int kFftBufBytes = 32 * kPlaneStride * 4; // 4608 per half-wavefront
+// epilogue half P, float2 cells: Z_g[128P + j] at g*128 + j (j < 128), Z_g[512 - 128P - j] at 256 + g*130 + j (j <= 128)
+constexpr int kMirrorBase = 256, kMirrorStride = 130;
+static_assert((kMirrorBase + 2 * kMirrorStride) * 8 <= kFftBufBytes, "epilogue must fit the transpose buffer");
+constexpr int kTwBytes = 16 * 32 * 8;               // W_512^(l*k1) as [k1][l] float2
+constexpr int kWinStride = 20;                      // window as [l][kWinStride]: lane l reads w[32a + l], a = 0..15
+constexpr int kWinBytes = 32 * kWinStride * 4;
+constexpr int kLdsBytes = kTwBytes + kWinBytes + kWaves * 2 * kFftBufBytes;
+
+__device__ constexpr float kC32[16] = {1.0f,          0.98078528040323044913f, 0.92387953251128675613f, 0.83146961230254523708f,
+                                       0.70710678118654752440f, 0.55557023301960222474f, 0.38268343236508977173f, 0.19509032201612826785f,
+                                       0.0f,          -0.19509032201612826785f, -0.38268343236508977173f, -0.55557023301960222474f,
+                                       -0.70710678118654752440f, -0.83146961230254523708f, -0.92387953251128675613f, -0.98078528040323044913f};
+__device__ constexpr float kS32[16] = {0.0f,          0.19509032201612826785f, 0.38268343236508977173f, 0.55557023301960222474f,
+                                       0.70710678118654752440f, 0.83146961230254523708f, 0.92387953251128675613f, 0.98078528040323044913f,
+                                       1.0f,          0.98078528040323044913f, 0.92387953251128675613f, 0.83146961230254523708f,
+                                       0.70710678118654752440f, 0.55557023301960222474f, 0.38268343236508977173f, 0.19509032201612826785f};
+
+__host__ __device__ constexpr int brev5(int v) {
+  return ((v & 1) << 4) | ((v & 2) << 2) | (v & 4) | ((v & 8) >> 2) | ((v & 16) >> 4);
+}
+__host__ __device__ constexpr int brev4(int v) { return ((v & 1) << 3) | ((v & 2) << 1) | ((v & 4) >> 1) | ((v & 8) >> 3); }
+
+// The first STAGES stages of the in-register radix-2 decimation-in-time network on 32 values (input in bit-reversed
+// order within each group of 2^STAGES registers): STAGES = 5 is a 32-point transform, STAGES = 4 two independent
+// 16-point transforms on registers 0..15 and 16..31.
+template <int STAGES>
+__device__ __forceinline__ void dit32(float (&re)[32], float (&im)[32]) {
+#pragma unroll
+  for (int s = 0; s < STAGES; ++s) {
+    const int half = 1 << s;
+#pragma unroll
+    for (int g = 0; g < 32; g += 2 * half) {
+#pragma unroll
+      for (int j = 0; j < half; ++j) {
+        const int t = j * (16 >> s);  // twiddle W_32^t = (C, -S)
+        const int i0 = g + j, i1 = i0 + half;
+        const float ar = re[i0], ai = im[i0], br = re[i1], bi = im[i1];
+        if (t == 0) {
+          re[i0] = ar + br; im[i0] = ai + bi;
+          re[i1] = ar - br; im[i1] = ai - bi;
+        } else if (t == 8) {  // w = -i
+          re[i0] = ar + bi; im[i0] = ai - br;
+          re[i1] = ar - bi; im[i1] = ai + br;
+        } else {
+          const float C = kC32[t], S = kS32[t];
+          const float o1r = __builtin_fmaf(S, bi, __builtin_fmaf(C, br, ar));
+          const float o1i = __builtin_fmaf(-S, br, __builtin_fmaf(C, bi, ai));
+          re[i0] = o1r; im[i0] = o1i;
+          re[i1] = __builtin_fmaf(2.0f, ar, -o1r);
+          im[i1] = __builtin_fmaf(2.0f, ai, -o1i);
+        }
+      }
+    }
+  }
+}
+
+__device__ __forceinline__ void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <typename In>
+__device__ __forceinline__ float ld(const In* p, int i);
+template <>
+__device__ __forceinline__ float ld<float>(const float* p, int i) {
+  return p[i];
+}
+template <>
+__device__ __forceinline__ float ld<int16_t>(const int16_t* p, int i) {
+  return (float)p[i] * (1.0f / 32768.0f);
+}
+
+template <bool PLUGIN, int BYTE>
+__device__ __forceinline__ uint32_t put_index(float msq, const FastScale& fs, uint32_t acc) {
+  if constexpr (PLUGIN) {
+    return acc | (fast_index(msq, fs) << (8 * BYTE));
+  } else {
+    const float t = __builtin_floorf(__builtin_fmaf(__log2f(msq), fs.a, fs.b));
+    return __builtin_amdgcn_cvt_pk_u8_f32(t, BYTE, acc);  // saturates to [0,255]; NaN -> 0
+  }
+}
+
+template <bool PLUGIN, typename In, bool FEAT, int HOP32>
+__global__ __launch_bounds__(kWaves * 64) void stft512_kernel(StftParams p, FastScale fs, const float2* __restrict__ tw_table) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float2* tw_lds = reinterpret_cast<float2*>(smem);
+  float* win_lds = reinterpret_cast<float*>(smem + kTwBytes);
+  for (int i = threadIdx.x; i < 512; i += kWaves * 64) {
+    tw_lds[i] = tw_table[i];
+    win_lds[(i & 31) * kWinStride + (i >> 5)] = p.window[i];  // sample n = 32a + l at [l][a]
+  }
+  __syncthreads();
+
+  const int lane = threadIdx.x & 63, l = lane & 31, h = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  unsigned char* fbuf = smem + kTwBytes + kWinBytes + (wave * 2 + h) * kFftBufBytes;
+  float* plane = reinterpret_cast<float*>(fbuf);
+  float2* cell = reinterpret_cast<float2*>(fbuf);  // epilogue view
+  const float4* win_row = reinterpret_cast<const float4*>(win_lds + l * kWinStride);
+  const In* __restrict__ x = reinterpret_cast<const In*>(p.pcm);
+  uint8_t* __restrict__ out = reinterpret_cast<uint8_t*>(p.out);
+  // blocks with equal blockIdx % 8 share an XCD (and its L2): give them neighbouring frame ranges
+  const uint32_t per = gridDim.x >> 3;
+  const uint32_t vb = (gridDim.x & 7) ? blockIdx.x : (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+  const uint64_t nunits = (p.nframes + 7) >> 3;  // a wavefront takes 8 consecutive frames, a half-wavefront 4 of them
+  const int gsel = l >> 4, k1 = l & 15;          // after the transpose: transform and first-pass output of this lane
+
+  for (uint64_t unit = (uint64_t)vb * kWaves + wave; unit < nunits; unit += (uint64_t)gridDim.x * kWaves) {
+    const uint64_t f0 = unit * 8 + 4 * h;  // this half-wavefront's frames are f0 .. f0+3
+    // The four frames transformed are fb .. fb+3: A = (fb, fb+1), B = (fb+2, fb+3).  At the end of the recording the
+    // block is shifted back so that every load stays in bounds; frames before f0 (another half-wavefront's) and
+    // past the end are not stored.
+    const uint64_t fb = f0 + 4 <= p.nframes ? f0 : p.nframes - 4;
+    float re[32], im[32];
+    {
+      float win[16];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float4 v = win_row[j];
+        win[4 * j] = v.x; win[4 * j + 1] = v.y; win[4 * j + 2] = v.z; win[4 * j + 3] = v.w;
+      }
+      const In* x0 = x + (p.frame0 + fb) * p.hop + l;
+      if constexpr (HOP32 > 0) {
+        float raw[16 + 3 * HOP32];
+#pragma unroll
+        for (int a = 0; a < 16 + 3 * HOP32; ++a) raw[a] = ld<In>(x0, 32 * a);
+#pragma unroll
+        for (int a = 0; a < 16; ++a) {
+          re[brev4(a)] = raw[a] * win[a];
+          im[brev4(a)] = raw[a + HOP32] * win[a];
+          re[16 + brev4(a)] = raw[a + 2 * HOP32] * win[a];
+          im[16 + brev4(a)] = raw[a + 3 * HOP32] * win[a];
+        }
+      } else {
+        const In *x1 = x0 + p.hop, *x2 = x1 + p.hop, *x3 = x2 + p.hop;
+#pragma unroll
+        for (int a = 0; a < 16; ++a) {
+          re[brev4(a)] = ld<In>(x0, 32 * a) * win[a];
+          im[brev4(a)] = ld<In>(x1, 32 * a) * win[a];
+          re[16 + brev4(a)] = ld<In>(x2, 32 * a) * win[a];
+          im[16 + brev4(a)] = ld<In>(x3, 32 * a) * win[a];
+        }
+      }
+    }
+    dit32<4>(re, im);  // Y_l[k1] of A in registers k1, of B in 16 + k1
+#pragma unroll
+    for (int r = 0; r < 32; ++r) {
+      if ((r & 15) == 0) continue;
+      const float2 t = tw_lds[(r & 15) * 32 + l];
+      const float ur = __builtin_fmaf(re[r], t.x, -im[r] * t.y);
+      const float ui = __builtin_fmaf(re[r], t.y, im[r] * t.x);
+      re[r] = ur;
+      im[r] = ui;
+    }
+    // transpose lane l, register r -> lane r, register l; the planes go through one buffer one after the other
+#pragma unroll
+    for (int r = 0; r < 32; ++r) plane[r * kPlaneStride + l] = re[r];
+    wave_sync();
+    {
+      const float4* row = reinterpret_cast<const float4*>(plane + l * kPlaneStride);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float4 v = row[j];
+        re[brev5(4 * j)] = v.x; re[brev5(4 * j + 1)] = v.y; re[brev5(4 * j + 2)] = v.z; re[brev5(4 * j + 3)] = v.w;
+      }
+    }
+    wave_sync();
+#pragma unroll
+    for (int r = 0; r < 32; ++r) plane[r * kPlaneStride + l] = im[r];
+    wave_sync();
+    {
+      const float4* row = reinterpret_cast<const float4*>(plane + l * kPlaneStride);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float4 v = row[j];
+        im[brev5(4 * j)] = v.x; im[brev5(4 * j + 1)] = v.y; im[brev5(4 * j + 2)] = v.z; im[brev5(4 * j + 3)] = v.w;
+      }
+    }
+    wave_sync();
+    dit32<5>(re, im);  // register k2 = Z_g[k1 + 16*k2], g = gsel
+
+    // Epilogue in two halves of 128 bins.  Lane (g, k1) holds Z_g[k1 + 16*k2] in register k2: for half P the
+    // registers 8P..8P+7 go to cell g*128 + (k - 128P), and the partners Z_g[512 - j], j = 128P..128P+128, sit in
+    // registers 24-8P..31-8P (j = 256 - k1 - 16*(k2 - 16)); the two ends of that range are one register off:
+    // j = 0 is Z[0] (register 0 of lane k1 = 0) and j = 128 of half 1 is Z[384] (register 24 of lane k1 = 0).
+    float best[4] = {-1.0f, -1.0f, -1.0f, -1.0f};  // FEAT: largest |X|^2 so far of frame 2q + {0, 1}, q = transform read
+    int kbest[4] = {(int)p.bin_lo, (int)p.bin_lo, (int)p.bin_lo, (int)p.bin_lo};
+#pragma unroll
+    for (int P = 0; P < 2; ++P) {
+      float2* lz = cell + gsel * 128;
+      float2* mz = cell + kMirrorBase + gsel * kMirrorStride;
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        lz[k1 + 16 * r] = make_float2(re[8 * P + r], im[8 * P + r]);
+        // register 24 - 8P + r: Z[256 + k1 + 16*(8 - 8P + r)], j = 128 + 128P - k1 - 16r, cell j - 128P
+        mz[128 - k1 - 16 * r] = make_float2(re[24 - 8 * P + r], im[24 - 8 * P + r]);
+      }
+      if (k1 == 0) mz[0] = P ? make_float2(re[24], im[24]) : make_float2(re[0], im[0]);
+      wave_sync();
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {  // transform q, bins 128P + 4l .. +3
+        const int k = 128 * P + 4 * l;
+        const float2* lr = cell + q * 128 + 4 * l;
+        const float2* mr = cell + kMirrorBase + q * kMirrorStride + 4 * l;
+        const float4 z01 = *reinterpret_cast<const float4*>(lr);
+        const float4 z23 = *reinterpret_cast<const float4*>(lr + 2);
+        const float4 q01 = *reinterpret_cast<const float4*>(mr);
+        const float4 q23 = *reinterpret_cast<const float4*>(mr + 2);
+        uint32_t wa = 0, wb = 0;
+        const bool in_band = k >= (int)p.bin_lo && k < (int)p.bin_hi;
+#define SONO_BIN(B, ZR, ZI, PR, PI)                                                              \
+  {                                                                                              \
+    const float ar = (ZR) + (PR), ai = (ZI) - (PI);                                              \
+    const float br = (ZI) + (PI), bi = (PR) - (ZR);                                              \
+    const float ma = __builtin_fmaf(ar, ar, ai * ai);                                            \
+    const float mb = __builtin_fmaf(br, br, bi * bi);                                            \
+    if constexpr (FEAT) { /* a lane visits the bins of a frame in ascending order */             \
+      if (in_band && ma > best[2 * q]) { best[2 * q] = ma; kbest[2 * q] = k + B; }               \
+      if (in_band && mb > best[2 * q + 1]) { best[2 * q + 1] = mb; kbest[2 * q + 1] = k + B; }   \
+    } else {                                                                                     \
+      wa = put_index<PLUGIN, B>(ma, fs, wa);                                                     \
+      wb = put_index<PLUGIN, B>(mb, fs, wb);                                                     \
+    }                                                                                            \
+  }
+        SONO_BIN(0, z01.x, z01.y, q01.x, q01.y)
+        SONO_BIN(1, z01.z, z01.w, q01.z, q01.w)
+        SONO_BIN(2, z23.x, z23.y, q23.x, q23.y)
+        SONO_BIN(3, z23.z, z23.w, q23.z, q23.w)
+#undef SONO_BIN
+        if (!FEAT && in_band) {
+          const uint64_t fa = fb + 2 * q;
+          const uint64_t row_a = (p.col0 + fa) * p.out_bins, row_b = row_a + p.out_bins;
+          const uint32_t col = k - p.out_bin0;
+          if (fa >= f0 && fa < p.nframes) *reinterpret_cast<uint32_t*>(out + row_a + col) = wa;
+          if (fa + 1 >= f0 && fa + 1 < p.nframes) *reinterpret_cast<uint32_t*>(out + row_b + col) = wb;
+        }
+      }
+      wave_sync();  // the buffer is rewritten by the next half / the next iteration's transpose
+    }
+    if constexpr (FEAT) {
+      // larger |X|^2 wins, equal values go to the lower bin
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int m = 1; m < 32; m <<= 1) {
+          const float o = __shfl_xor(best[i], m, 64);
+          const int ko = __shfl_xor(kbest[i], m, 64);
+          if (o > best[i] || (o == best[i] && ko < kbest[i])) { best[i] = o; kbest[i] = ko; }
+        }
+        const uint64_t fr = fb + i;
+        if (l == 0 && fr >= f0 && fr < p.nframes) {
+          sono_frame_feature r{};
+          r.peak_bin = kbest[i];
+          r.peak_idx = (uint8_t)put_index<PLUGIN, 0>(best[i], fs, 0);
+          reinterpret_cast<sono_frame_feature*>(p.out)[p.col0 + fr] = r;
+        }
+      }
+    }
+  }
+}
+
+}  // namespace fast512
+
+// W_512^(l*k1) as [k1][l] float2 (cos, -sin), k1 < 16, l < 32, computed in double.
+void build_fast_table_512(std::vector<float>& t) {
+  t.resize(2 * 512);
+  const double pi = 3.141592653589793;
+  for (int k1 = 0; k1 < 16; ++k1)
+    for (int l = 0; l < 32; ++l) {
+      const double ang = -2.0 * pi * (double)(k1 * l) / 512.0;
+      t[2 * (k1 * 32 + l)] = (float)std::cos(ang);
+      t[2 * (k1 * 32 + l) + 1] = (float)std::sin(ang);
+    }
+}
+
+bool fast512_available(const StftParams& p) {
+  if (p.n != 512 || p.fast_mode != 1 || !p.fast_table || p.nframes < 8) return false;
+  if ((p.bin_lo & 3) || (p.bin_hi & 3) || p.bin_lo >= p.bin_hi) return false;
+  if (p.out_kind == SONO_OUT_FEATURES) return true;
+  if (p.out_kind != SONO_OUT_U8_INDEX) return false;
+  return !(p.out_bins & 3) && !(p.out_bin0 & 3) && !(reinterpret_cast<uintptr_t>(p.out) & 3);
+}
+
+// Returns 1 if this launch is not served here.
+int launch_stft_fast512(const StftParams& p, void* stream_v) {
+  using namespace fast512;
+  if (!fast512_available(p)) return 1;
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_v);
+  FastScale fs = make_fast_scale(p.scale_mode, p.n, p.gain_db, p.range_db);
+  fs.b -= 2.0f * fs.a;  // the pair separation leaves 2*X: |2X|^2 = 4|X|^2
+  int dev = 0, cus = 256;
+  hipDeviceProp_t prop;
+  if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+    cus = prop.multiProcessorCount;
+  const uint64_t nunits = (p.nframes + 7) / 8;
+  const uint64_t need = (nunits + kWaves - 1) / kWaves;
+  const uint32_t grid = (uint32_t)(need < (uint64_t)cus ? need : (uint64_t)cus);  // persistent: one workgroup per CU
+  const float2* table = reinterpret_cast<const float2*>(p.fast_table);
+  const bool plugin = p.scale_mode == SONO_SCALE_PLUGIN_DB, i16 = p.in_kind == SONO_IN_I16, feat = p.out_kind == SONO_OUT_FEATURES;
+#define SONO_L512(PL, In, FE, H)                                                                                 \
+  do {                                                                                                          \
+    auto kern = stft512_kernel<PL, In, FE, H>;                                                                  \
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,    \
+                            kLdsBytes) != hipSuccess)                                                           \
+      return SONO_ERR_DEVICE;                                                                                   \
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kWaves * 64), kLdsBytes, stream, p, fs, table);                   \
+  } while (0)
+#define SONO_L512_F(PL, In)                                                                                   \
+  do {                                                                                                        \
+    if (p.hop == 128) { if (feat) SONO_L512(PL, In, true, 4); else SONO_L512(PL, In, false, 4); }              \
+    else { if (feat) SONO_L512(PL, In, true, 0); else SONO_L512(PL, In, false, 0); }                           \
+  } while (0)
+  if (plugin) { if (i16) SONO_L512_F(true, int16_t); else SONO_L512_F(true, float); }
+  else { if (i16) SONO_L512_F(false, int16_t); else SONO_L512_F(false, float); }
+#undef SONO_L512_F
+#undef SONO_L512
+  return hipGetLastError() == hipSuccess ? SONO_OK : SONO_ERR_DEVICE;
+}
+
+}  // namespace sono

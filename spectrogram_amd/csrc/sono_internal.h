@@ -54,6 +54,10 @@ int launch_stft_general(const StftParams& p, bool exact_f64, void* hip_stream);
 // kernels_fast.hip: float32 kernels with accurate twiddles (returns 1 if this size/mode has no fast kernel).
 int launch_stft_fast(const StftParams& p, void* hip_stream);
 void build_fast_table_1024(std::vector<float>& t);
+// kernels_fast512.hip: float32 kernel for 512-point frames with exact roots of unity (fast_mode 1, fast_table from
+// build_fast_table_512); colour indices and per-frame peaks.  Returns 1 if it does not serve this launch.
+int launch_stft_fast512(const StftParams& p, void* hip_stream);
+void build_fast_table_512(std::vector<float>& t);
 // kernels_mw.hip: float32 kernel for 2048- and 4096-point frames with the context's twiddle table
 // (returns 1 if it does not serve this size / layout).
 int launch_stft_mw(const StftParams& p, void* hip_stream);
