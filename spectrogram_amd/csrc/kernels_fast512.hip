@@ -134,7 +134,6 @@ __global__ __launch_bounds__(kWaves * 64) void stft512_kernel(StftParams p, Fast
   const uint32_t per = gridDim.x >> 3;
   const uint32_t vb = (gridDim.x & 7) ? blockIdx.x : (blockIdx.x & 7) * per + (blockIdx.x >> 3);
   const uint64_t nunits = (p.nframes + 7) >> 3;  // a wavefront takes 8 consecutive frames, a half-wavefront 4 of them
-  const int gsel = l >> 4, k1 = l & 15;          // after the transpose: transform and first-pass output of this lane
 
   for (uint64_t unit = (uint64_t)vb * kWaves + wave; unit < nunits; unit += (uint64_t)gridDim.x * kWaves) {
     const uint64_t f0 = unit * 8 + 4 * h;  // this half-wavefront's frames are f0 .. f0+3
@@ -210,29 +209,34 @@ __global__ __launch_bounds__(kWaves * 64) void stft512_kernel(StftParams p, Fast
     wave_sync();
     dit32<5>(re, im);  // register k2 = Z_g[k1 + 16*k2], g = gsel
 
-    // Epilogue in two halves of 128 bins.  Lane (g, k1) holds Z_g[k1 + 16*k2] in register k2: for half P the
+    // Epilogue in two halves of 128 bins.  After the transpose lane 16g + k1 holds Z_g[k1 + 16*k2] in register k2: for half P the
     // registers 8P..8P+7 go to cell g*128 + (k - 128P), and the partners Z_g[512 - j], j = 128P..128P+128, sit in
     // registers 24-8P..31-8P (j = 256 - k1 - 16*(k2 - 16)); the two ends of that range are one register off:
     // j = 0 is Z[0] (register 0 of lane k1 = 0) and j = 128 of half 1 is Z[384] (register 24 of lane k1 = 0).
+    // (everything derived from the lane below is invariant in the frame loop; the empty asm keeps the compiler from
+    // hoisting those addresses into registers that the transforms need -- they would be spilled)
+    int le = l;
+    asm volatile("" : "+v"(le));
     float best[4] = {-1.0f, -1.0f, -1.0f, -1.0f};  // FEAT: largest |X|^2 so far of frame 2q + {0, 1}, q = transform read
     int kbest[4] = {(int)p.bin_lo, (int)p.bin_lo, (int)p.bin_lo, (int)p.bin_lo};
 #pragma unroll
     for (int P = 0; P < 2; ++P) {
-      float2* lz = cell + gsel * 128;
-      float2* mz = cell + kMirrorBase + gsel * kMirrorStride;
+      const int ge = le >> 4, ke = le & 15;
+      float2* lz = cell + ge * 128;
+      float2* mz = cell + kMirrorBase + ge * kMirrorStride;
 #pragma unroll
       for (int r = 0; r < 8; ++r) {
-        lz[k1 + 16 * r] = make_float2(re[8 * P + r], im[8 * P + r]);
+        lz[ke + 16 * r] = make_float2(re[8 * P + r], im[8 * P + r]);
         // register 24 - 8P + r: Z[256 + k1 + 16*(8 - 8P + r)], j = 128 + 128P - k1 - 16r, cell j - 128P
-        mz[128 - k1 - 16 * r] = make_float2(re[24 - 8 * P + r], im[24 - 8 * P + r]);
+        mz[128 - ke - 16 * r] = make_float2(re[24 - 8 * P + r], im[24 - 8 * P + r]);
       }
-      if (k1 == 0) mz[0] = P ? make_float2(re[24], im[24]) : make_float2(re[0], im[0]);
+      if (ke == 0) mz[0] = P ? make_float2(re[24], im[24]) : make_float2(re[0], im[0]);
       wave_sync();
 #pragma unroll
       for (int q = 0; q < 2; ++q) {  // transform q, bins 128P + 4l .. +3
-        const int k = 128 * P + 4 * l;
-        const float2* lr = cell + q * 128 + 4 * l;
-        const float2* mr = cell + kMirrorBase + q * kMirrorStride + 4 * l;
+        const int k = 128 * P + 4 * le;
+        const float2* lr = cell + q * 128 + 4 * le;
+        const float2* mr = cell + kMirrorBase + q * kMirrorStride + 4 * le;
         const float4 z01 = *reinterpret_cast<const float4*>(lr);
         const float4 z23 = *reinterpret_cast<const float4*>(lr + 2);
         const float4 q01 = *reinterpret_cast<const float4*>(mr);
