@@ -309,7 +309,6 @@ static uint64_t in_bytes(const sono_ctx* c, uint64_t L) { return L * (c->cfg.in_
 static uint32_t fast_mode_of(const sono_ctx* c) {
   if (c->cfg.arith != SONO_ARITH_FAST_F32 || (c->cfg.fft_n != 1024 && c->cfg.fft_n != 512) || c->d_fb_bin) return 0;
   if (c->cfg.twiddle_mode == SONO_TW_ACCURATE && !c->host_twiddles) return c->d_fast ? 1 : 0;
-  if (c->cfg.fft_n != 1024) return 0;  // table twiddles: the 1024-point kernel only
   // table twiddles: the kernel folds the first butterfly of every stage, so that factor must be 1
   for (uint32_t T = 1; T < c->cfg.fft_n; T <<= 1)
     if (c->h_cos[T - 1] != 1.0 || c->h_sin[T - 1] != 0.0) return 0;

@@ -1,5 +1,5 @@
-// Float32 STFT kernel for 512-point frames with exact roots of unity (the worker path at the page's default FFT
-// size, main.js:886-889; spectrogramWorker.js:38-99,206-253).  Compile with -ffp-contract=fast.
+// Float32 STFT kernel for 512-point frames, the page's default FFT size (main.js:886-889): the worker path with exact
+// roots of unity (spectrogramWorker.js:38-99,206-253) and the plugin path with its twiddle table (spectrogram.esm.js:166-200).  Compile with -ffp-contract=fast.
 //
 // Same machine mapping as the 1024-point kernel, with two transforms per half-wavefront:
 //   * a half-wavefront (32 lanes) transforms FOUR real frames as two complex 512-point frames A and B
@@ -84,6 +84,38 @@ __device__ __forceinline__ void dit32(float (&re)[32], float (&im)[32]) {
   }
 }
 
+// The same network with factors from a table (the plugin's recurrence factors or a host table, which are not exact
+// roots of unity: every butterfly must use the very factor the reference uses, spectrogram.esm.js:176-190).
+// tw(half, j): factor (cos, sin) of the butterfly at position j of a stage with half size `half`.  FIRST: these are
+// the first stages of the transform, where j == 0 is the factor (1, 0) exactly in every table the kernel accepts.
+template <int STAGES, bool FIRST, class TwFn>
+__device__ __forceinline__ void dit32_table(float (&re)[32], float (&im)[32], TwFn tw) {
+#pragma unroll
+  for (int s = 0; s < STAGES; ++s) {
+    const int half = 1 << s;
+#pragma unroll
+    for (int j = 0; j < half; ++j) {
+      float2 w = make_float2(1.0f, 0.0f);
+      if (!FIRST || j != 0) w = tw(half, j);
+#pragma unroll
+      for (int g = 0; g < 32; g += 2 * half) {
+        const int i0 = g + j, i1 = i0 + half;
+        const float ar = re[i0], ai = im[i0], br = re[i1], bi = im[i1];
+        if (FIRST && j == 0) {
+          re[i0] = ar + br; im[i0] = ai + bi;
+          re[i1] = ar - br; im[i1] = ai - bi;
+        } else {  // o1 = a + w*b, o2 = a - w*b = 2a - o1
+          const float o1r = __builtin_fmaf(-w.y, bi, __builtin_fmaf(w.x, br, ar));
+          const float o1i = __builtin_fmaf(w.y, br, __builtin_fmaf(w.x, bi, ai));
+          re[i0] = o1r; im[i0] = o1i;
+          re[i1] = __builtin_fmaf(2.0f, ar, -o1r);
+          im[i1] = __builtin_fmaf(2.0f, ai, -o1i);
+        }
+      }
+    }
+  }
+}
+
 __device__ __forceinline__ void wave_sync() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
@@ -111,13 +143,27 @@ __device__ __forceinline__ uint32_t put_index(float msq, const FastScale& fs, ui
   }
 }
 
-template <bool PLUGIN, typename In, bool FEAT, int HOP32>
+// TABLE: the context's per-stage twiddle table (flat layout, the stage with half size T at [T-1, 2T-1)) instead of
+// exact roots.  Lane l's registers are the 16 consecutive bit-reversed positions 16*brev5(l) + brev4(a), so the
+// first pass is the reference's stages T = 1..8 (factors wave-uniform) and, after the transpose, the second pass its
+// stages T = 16..256 with the factor 16*(g mod t) + k1 of stage T = 16t, read from a [31][16] copy in LDS; there is
+// no multiplication between the passes.
+template <bool PLUGIN, typename In, bool FEAT, int HOP32, bool TABLE>
 __global__ __launch_bounds__(kWaves * 64) void stft512_kernel(StftParams p, FastScale fs, const float2* __restrict__ tw_table) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float2* tw_lds = reinterpret_cast<float2*>(smem);
   float* win_lds = reinterpret_cast<float*>(smem + kTwBytes);
+  const float2* __restrict__ tw_flat = reinterpret_cast<const float2*>(p.twiddles);
   for (int i = threadIdx.x; i < 512; i += kWaves * 64) {
-    tw_lds[i] = tw_table[i];
+    if constexpr (TABLE) {
+      const int r = i >> 4, kk = i & 15;  // row r = t - 1 + j of the second pass: stage T = 16t, factor 16j + kk
+      if (r < 31) {
+        const int t = 1 << (31 - __builtin_clz(r + 1)), j = r + 1 - t;
+        tw_lds[i] = tw_flat[16 * t - 1 + 16 * j + kk];
+      }
+    } else {
+      tw_lds[i] = tw_table[i];
+    }
     win_lds[(i & 31) * kWinStride + (i >> 5)] = p.window[i];  // sample n = 32a + l at [l][a]
   }
   __syncthreads();
@@ -172,15 +218,19 @@ __global__ __launch_bounds__(kWaves * 64) void stft512_kernel(StftParams p, Fast
         }
       }
     }
-    dit32<4>(re, im);  // Y_l[k1] of A in registers k1, of B in 16 + k1
+    if constexpr (TABLE) {
+      dit32_table<4, true>(re, im, [&](int half, int j) { return tw_flat[half - 1 + j]; });  // stages T = 1..8, wave-uniform
+    } else {
+      dit32<4>(re, im);  // Y_l[k1] of A in registers k1, of B in 16 + k1
 #pragma unroll
-    for (int r = 0; r < 32; ++r) {
-      if ((r & 15) == 0) continue;
-      const float2 t = tw_lds[(r & 15) * 32 + l];
-      const float ur = __builtin_fmaf(re[r], t.x, -im[r] * t.y);
-      const float ui = __builtin_fmaf(re[r], t.y, im[r] * t.x);
-      re[r] = ur;
-      im[r] = ui;
+      for (int r = 0; r < 32; ++r) {
+        if ((r & 15) == 0) continue;
+        const float2 t = tw_lds[(r & 15) * 32 + l];
+        const float ur = __builtin_fmaf(re[r], t.x, -im[r] * t.y);
+        const float ui = __builtin_fmaf(re[r], t.y, im[r] * t.x);
+        re[r] = ur;
+        im[r] = ui;
+      }
     }
     // transpose lane l, register r -> lane r, register l; the planes go through one buffer one after the other
 #pragma unroll
@@ -207,7 +257,13 @@ __global__ __launch_bounds__(kWaves * 64) void stft512_kernel(StftParams p, Fast
       }
     }
     wave_sync();
-    dit32<5>(re, im);  // register k2 = Z_g[k1 + 16*k2], g = gsel
+    if constexpr (TABLE) {
+      int kt = l & 15;
+      asm volatile("" : "+v"(kt));  // (keeps the 31 factor addresses out of registers across the loop)
+      dit32_table<5, false>(re, im, [&](int half, int j) { return tw_lds[(half - 1 + j) * 16 + kt]; });  // stages T = 16..256
+    } else {
+      dit32<5>(re, im);  // register k2 = Z_g[k1 + 16*k2] in lane 16g + k1
+    }
 
     // Epilogue in two halves of 128 bins.  After the transpose lane 16g + k1 holds Z_g[k1 + 16*k2] in register k2: for half P the
     // registers 8P..8P+7 go to cell g*128 + (k - 128P), and the partners Z_g[512 - j], j = 128P..128P+128, sit in
@@ -309,7 +365,8 @@ void build_fast_table_512(std::vector<float>& t) {
 }
 
 bool fast512_available(const StftParams& p) {
-  if (p.n != 512 || p.fast_mode != 1 || !p.fast_table || p.nframes < 8) return false;
+  if (p.n != 512 || p.nframes < 8) return false;
+  if (!((p.fast_mode == 1 && p.fast_table) || (p.fast_mode == 2 && p.twiddles))) return false;
   if ((p.bin_lo & 3) || (p.bin_hi & 3) || p.bin_lo >= p.bin_hi) return false;
   if (p.out_kind == SONO_OUT_FEATURES) return true;
   if (p.out_kind != SONO_OUT_U8_INDEX) return false;
@@ -332,9 +389,10 @@ int launch_stft_fast512(const StftParams& p, void* stream_v) {
   const uint32_t grid = (uint32_t)(need < (uint64_t)cus ? need : (uint64_t)cus);  // persistent: one workgroup per CU
   const float2* table = reinterpret_cast<const float2*>(p.fast_table);
   const bool plugin = p.scale_mode == SONO_SCALE_PLUGIN_DB, i16 = p.in_kind == SONO_IN_I16, feat = p.out_kind == SONO_OUT_FEATURES;
-#define SONO_L512(PL, In, FE, H)                                                                                 \
+  const bool tab = p.fast_mode == 2;
+#define SONO_L512(PL, In, FE, H, T)                                                                              \
   do {                                                                                                          \
-    auto kern = stft512_kernel<PL, In, FE, H>;                                                                  \
+    auto kern = stft512_kernel<PL, In, FE, H, T>;                                                                \
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,    \
                             kLdsBytes) != hipSuccess)                                                           \
       return SONO_ERR_DEVICE;                                                                                   \
@@ -342,8 +400,13 @@ int launch_stft_fast512(const StftParams& p, void* stream_v) {
   } while (0)
 #define SONO_L512_F(PL, In)                                                                                   \
   do {                                                                                                        \
-    if (p.hop == 128) { if (feat) SONO_L512(PL, In, true, 4); else SONO_L512(PL, In, false, 4); }              \
-    else { if (feat) SONO_L512(PL, In, true, 0); else SONO_L512(PL, In, false, 0); }                           \
+    if (tab) {                                                                                                \
+      if (p.hop == 128) { if (feat) SONO_L512(PL, In, true, 4, true); else SONO_L512(PL, In, false, 4, true); } \
+      else { if (feat) SONO_L512(PL, In, true, 0, true); else SONO_L512(PL, In, false, 0, true); }             \
+    } else {                                                                                                  \
+      if (p.hop == 128) { if (feat) SONO_L512(PL, In, true, 4, false); else SONO_L512(PL, In, false, 4, false); } \
+      else { if (feat) SONO_L512(PL, In, true, 0, false); else SONO_L512(PL, In, false, 0, false); }           \
+    }                                                                                                         \
   } while (0)
   if (plugin) { if (i16) SONO_L512_F(true, int16_t); else SONO_L512_F(true, float); }
   else { if (i16) SONO_L512_F(false, int16_t); else SONO_L512_F(false, float); }
