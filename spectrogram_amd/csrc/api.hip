@@ -201,9 +201,9 @@ sono_ctx* sono_create(int device, const sono_config* cfg) {
     sono_destroy(c);
     return nullptr;
   }
-  if (cfg->arith == SONO_ARITH_FAST_F32 && cfg->twiddle_mode == SONO_TW_ACCURATE && (n == 1024 || n == 512)) {
+  if (cfg->arith == SONO_ARITH_FAST_F32 && cfg->twiddle_mode == SONO_TW_ACCURATE && (n == 1024 || n == 512 || n == 2048)) {
     std::vector<float> t;
-    if (n == 1024) build_fast_table_1024(t); else build_fast_table_512(t);
+    if (n == 1024) build_fast_table_1024(t); else if (n == 512) build_fast_table_512(t); else build_fast_table_2048(t);
     if ((e = hipMalloc(&c->d_fast, sizeof(float) * t.size())) != hipSuccess) return bail("hipMalloc(fast table)", e);
     if ((e = hipMemcpy(c->d_fast, t.data(), sizeof(float) * t.size(), hipMemcpyHostToDevice)) != hipSuccess)
       return bail("hipMemcpy(fast table)", e);
@@ -307,8 +307,10 @@ static uint64_t in_bytes(const sono_ctx* c, uint64_t L) { return L * (c->cfg.in_
 
 // Which flavour of the fast 1024-point kernel serves this context (StftParams::fast_mode).
 static uint32_t fast_mode_of(const sono_ctx* c) {
-  if (c->cfg.arith != SONO_ARITH_FAST_F32 || (c->cfg.fft_n != 1024 && c->cfg.fft_n != 512) || c->d_fb_bin) return 0;
+  const uint32_t fn = c->cfg.fft_n;
+  if (c->cfg.arith != SONO_ARITH_FAST_F32 || (fn != 1024 && fn != 512 && fn != 2048) || c->d_fb_bin) return 0;
   if (c->cfg.twiddle_mode == SONO_TW_ACCURATE && !c->host_twiddles) return c->d_fast ? 1 : 0;
+  if (fn == 2048) return 0;  // table twiddles: the 512- and 1024-point kernels only
   // table twiddles: the kernel folds the first butterfly of every stage, so that factor must be 1
   for (uint32_t T = 1; T < c->cfg.fft_n; T <<= 1)
     if (c->h_cos[T - 1] != 1.0 || c->h_sin[T - 1] != 0.0) return 0;
@@ -423,6 +425,7 @@ int sono_stft_async(sono_ctx* c, const void* pcm, uint64_t L, void* out, uint64_
           } else {
             r = launch_stft_fast(u, c->stream);
             if (r == 1) r = launch_stft_fast512(u, c->stream);
+            if (r == 1) r = launch_stft_fast2048(u, c->stream);
             if (r == 1) r = launch_stft_mw(u, c->stream);
             if (r == 1) r = launch_stft_general(u, false, c->stream);
           }
@@ -436,6 +439,7 @@ int sono_stft_async(sono_ctx* c, const void* pcm, uint64_t L, void* out, uint64_
     }
     if (fast_eligible(c)) r = launch_stft_fast(q, c->stream);
     if (r == 1 && fast_eligible(c)) r = launch_stft_fast512(q, c->stream);
+    if (r == 1 && fast_eligible(c)) r = launch_stft_fast2048(q, c->stream);
     if (r == 1 && q.mw_ok) r = launch_stft_mw(q, c->stream);
     if (exact) r = launch_stft_exact(q, c->stream);
     if (r == 1) r = launch_stft_general(q, exact, c->stream);

@@ -1,0 +1,396 @@
+// Float32 STFT kernel for 2048-point frames with exact roots of unity (the worker path at the page's largest FFT
+// size, main.js:886-889; spectrogramWorker.js:38-99,206-253).  Compile with -ffp-contract=fast.
+//
+// One wavefront (64 lanes x 32 registers) transforms TWO real frames as one complex 2048-point frame z = x0 + i*x1:
+//   * lane l holds samples 64a + l, a = 0..31; 2048 = 32 x 64: the first pass is a 32-point transform per lane
+//     (Y_l[k1]), then the twiddle W_2048^(l*k1);
+//   * a 32 x 64 transpose through LDS: lane k1 + 32*hb reads y[m + 32*hb], m = 0..31, of row k1;
+//   * the 64-point transform over l is decimated in frequency: one radix-2 stage ACROSS the two lanes of a row --
+//     two rounds of v_permlane32_swap leave the sums u_m = y[m] + y[m+32] (all 32 of them) in the upper lane of the
+//     pair and the differences d_m = y[m] - y[m+32] in the lower lane, which multiplies them by W_64^m -- and then one
+//     32-point transform per lane: the lower lane ends with Z[k1 + 32*(2*k2 + 1)], the upper with Z[k1 + 32*(2*k2)];
+//   * epilogue in two halves of 512 bins: registers 8P..8P+7 of all 64 lanes are Z[k], 512P <= k < 512P+512, registers
+//     24-8P..31-8P their partners Z[2048 - k]; both go through LDS in ascending k so that a lane reads four
+//     consecutive bins of both as 16-byte pieces, separates the two frames and fuses |X|^2 -> log2 -> quantiser.
+//   * HOP64 > 0: hop == 64*HOP64, so the two frames are one run of 32 + HOP64 loads.
+// Outputs: [frame][bin] colour indices, or per-frame spectral peaks.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <vector>
+
+#include "sono_device.h"
+#include "sono_internal.h"
+
+namespace sono {
+namespace fast2048 {
+
+constexpr int kWaves = 15;                          // wavefronts per workgroup (one workgroup per CU): 30 frames per iteration
+constexpr int kPlaneStride = 68;                    // floats per transpose row (64 + 4: rows stay 16-B aligned)
+constexpr int kBufBytes = 32 * kPlaneStride * 4;    // 8704 per wavefront
+constexpr int kMirrorBase = 512;                    // epilogue, float2 cells: Z[512P + j] at j, Z[2048 - 512P - j] at 512 + j (j <= 512)
+static_assert((kMirrorBase + 513) * 8 <= kBufBytes, "epilogue must fit the transpose buffer");
+constexpr int kTwBytes = 32 * 64 * 8;               // W_2048^(l*k1) as [k1][l] float2
+constexpr int kWinBytes = 2048 * 4;                 // window as stored: lane l reads w[64a + l]
+constexpr int kLdsBytes = kTwBytes + kWinBytes + kWaves * kBufBytes;
+static_assert(kLdsBytes <= 160 * 1024, "LDS of one CU");
+
+__device__ constexpr float kC32[16] = {1.0f,          0.98078528040323044913f, 0.92387953251128675613f, 0.83146961230254523708f,
+                                       0.70710678118654752440f, 0.55557023301960222474f, 0.38268343236508977173f, 0.19509032201612826785f,
+                                       0.0f,          -0.19509032201612826785f, -0.38268343236508977173f, -0.55557023301960222474f,
+                                       -0.70710678118654752440f, -0.83146961230254523708f, -0.92387953251128675613f, -0.98078528040323044913f};
+__device__ constexpr float kS32[16] = {0.0f,          0.19509032201612826785f, 0.38268343236508977173f, 0.55557023301960222474f,
+                                       0.70710678118654752440f, 0.83146961230254523708f, 0.92387953251128675613f, 0.98078528040323044913f,
+                                       1.0f,          0.98078528040323044913f, 0.92387953251128675613f, 0.83146961230254523708f,
+                                       0.70710678118654752440f, 0.55557023301960222474f, 0.38268343236508977173f, 0.19509032201612826785f};
+// cos/sin(2*pi*m/64), m = 0..31
+__device__ constexpr float kC64[32] = {
+    1.0f, 0.99518472667219688624f, 0.98078528040323044913f, 0.95694033573220886494f, 0.92387953251128675613f, 0.88192126434835502971f,
+    0.83146961230254523708f, 0.77301045336273696081f, 0.70710678118654752440f, 0.63439328416364549822f, 0.55557023301960222474f,
+    0.47139673682599764856f, 0.38268343236508977173f, 0.29028467725446236764f, 0.19509032201612826785f, 0.09801714032956060199f,
+    0.0f, -0.09801714032956060199f, -0.19509032201612826785f, -0.29028467725446236764f, -0.38268343236508977173f,
+    -0.47139673682599764856f, -0.55557023301960222474f, -0.63439328416364549822f, -0.70710678118654752440f, -0.77301045336273696081f,
+    -0.83146961230254523708f, -0.88192126434835502971f, -0.92387953251128675613f, -0.95694033573220886494f, -0.98078528040323044913f,
+    -0.99518472667219688624f};
+__device__ constexpr float kS64[32] = {
+    0.0f, 0.09801714032956060199f, 0.19509032201612826785f, 0.29028467725446236764f, 0.38268343236508977173f, 0.47139673682599764856f,
+    0.55557023301960222474f, 0.63439328416364549822f, 0.70710678118654752440f, 0.77301045336273696081f, 0.83146961230254523708f,
+    0.88192126434835502971f, 0.92387953251128675613f, 0.95694033573220886494f, 0.98078528040323044913f, 0.99518472667219688624f,
+    1.0f, 0.99518472667219688624f, 0.98078528040323044913f, 0.95694033573220886494f, 0.92387953251128675613f, 0.88192126434835502971f,
+    0.83146961230254523708f, 0.77301045336273696081f, 0.70710678118654752440f, 0.63439328416364549822f, 0.55557023301960222474f,
+    0.47139673682599764856f, 0.38268343236508977173f, 0.29028467725446236764f, 0.19509032201612826785f, 0.09801714032956060199f};
+
+__host__ __device__ constexpr int brev5(int v) {
+  return ((v & 1) << 4) | ((v & 2) << 2) | (v & 4) | ((v & 8) >> 2) | ((v & 16) >> 4);
+}
+
+// In-register 32-point forward DFT, radix-2 decimation in time: input in bit-reversed register order, output natural.
+__device__ __forceinline__ void fft32(float (&re)[32], float (&im)[32]) {
+#pragma unroll
+  for (int s = 0; s < 5; ++s) {
+    const int half = 1 << s;
+#pragma unroll
+    for (int g = 0; g < 32; g += 2 * half) {
+#pragma unroll
+      for (int j = 0; j < half; ++j) {
+        const int t = j * (16 >> s);  // twiddle W_32^t = (C, -S)
+        const int i0 = g + j, i1 = i0 + half;
+        const float ar = re[i0], ai = im[i0], br = re[i1], bi = im[i1];
+        if (t == 0) {
+          re[i0] = ar + br; im[i0] = ai + bi;
+          re[i1] = ar - br; im[i1] = ai - bi;
+        } else if (t == 8) {  // w = -i
+          re[i0] = ar + bi; im[i0] = ai - br;
+          re[i1] = ar - bi; im[i1] = ai + br;
+        } else {
+          const float C = kC32[t], S = kS32[t];
+          const float o1r = __builtin_fmaf(S, bi, __builtin_fmaf(C, br, ar));
+          const float o1i = __builtin_fmaf(-S, br, __builtin_fmaf(C, bi, ai));
+          re[i0] = o1r; im[i0] = o1i;
+          re[i1] = __builtin_fmaf(2.0f, ar, -o1r);
+          im[i1] = __builtin_fmaf(2.0f, ai, -o1i);
+        }
+      }
+    }
+  }
+}
+
+__device__ __forceinline__ void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// v_permlane32_swap: lanes 32..63 of a trade places with lanes 0..31 of b.
+__device__ __forceinline__ void swap32(float& a, float& b) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+  a = __uint_as_float(r[0]);
+  b = __uint_as_float(r[1]);
+}
+
+template <typename In>
+__device__ __forceinline__ float ld(const In* p, int i);
+template <>
+__device__ __forceinline__ float ld<float>(const float* p, int i) {
+  return p[i];
+}
+template <>
+__device__ __forceinline__ float ld<int16_t>(const int16_t* p, int i) {
+  return (float)p[i] * (1.0f / 32768.0f);
+}
+
+template <bool PLUGIN, int BYTE>
+__device__ __forceinline__ uint32_t put_index(float msq, const FastScale& fs, uint32_t acc) {
+  if constexpr (PLUGIN) {
+    return acc | (fast_index(msq, fs) << (8 * BYTE));
+  } else {
+    const float t = __builtin_floorf(__builtin_fmaf(__log2f(msq), fs.a, fs.b));
+    return __builtin_amdgcn_cvt_pk_u8_f32(t, BYTE, acc);  // saturates to [0,255]; NaN -> 0
+  }
+}
+
+template <bool PLUGIN, typename In, bool FEAT, int HOP64>
+__global__ __launch_bounds__(kWaves * 64) void stft2048_kernel(StftParams p, FastScale fs, const float2* __restrict__ tw_table) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float2* tw_lds = reinterpret_cast<float2*>(smem);
+  float* win_lds = reinterpret_cast<float*>(smem + kTwBytes);
+  for (int i = threadIdx.x; i < 2048; i += kWaves * 64) {
+    tw_lds[i] = tw_table[i];
+    win_lds[i] = p.window[i];
+  }
+  __syncthreads();
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  unsigned char* fbuf = smem + kTwBytes + kWinBytes + wave * kBufBytes;
+  float* plane = reinterpret_cast<float*>(fbuf);
+  float2* cell = reinterpret_cast<float2*>(fbuf);  // epilogue view
+  const In* __restrict__ x = reinterpret_cast<const In*>(p.pcm);
+  uint8_t* __restrict__ out = reinterpret_cast<uint8_t*>(p.out);
+  // blocks with equal blockIdx % 8 share an XCD (and its L2): give them neighbouring frame ranges
+  const uint32_t per = gridDim.x >> 3;
+  const uint32_t vb = (gridDim.x & 7) ? blockIdx.x : (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+  const uint64_t nunits = (p.nframes + 1) >> 1;  // a wavefront takes two consecutive frames
+
+  for (uint64_t unit = (uint64_t)vb * kWaves + wave; unit < nunits; unit += (uint64_t)gridDim.x * kWaves) {
+    const uint64_t f0 = unit * 2;
+    // the frames transformed are fb, fb + 1; an odd last frame is the second of the pair before it (frames before f0
+    // are another wavefront's and are not stored)
+    const uint64_t fb = f0 + 2 <= p.nframes ? f0 : p.nframes - 2;
+    float re[32], im[32];
+    {
+      const In* x0 = x + (p.frame0 + fb) * p.hop + lane;
+      if constexpr (HOP64 > 0) {
+        float raw[32 + HOP64];
+#pragma unroll
+        for (int a = 0; a < 32 + HOP64; ++a) raw[a] = ld<In>(x0, 64 * a);
+#pragma unroll
+        for (int a = 0; a < 32; ++a) {
+          const float w = win_lds[64 * a + lane];
+          re[brev5(a)] = raw[a] * w;
+          im[brev5(a)] = raw[a + HOP64] * w;
+        }
+      } else {
+        const In* x1 = x0 + p.hop;
+#pragma unroll
+        for (int a = 0; a < 32; ++a) {
+          const float w = win_lds[64 * a + lane];
+          re[brev5(a)] = ld<In>(x0, 64 * a) * w;
+          im[brev5(a)] = ld<In>(x1, 64 * a) * w;
+        }
+      }
+    }
+    fft32(re, im);  // Y_l[k1]
+#pragma unroll
+    for (int k1 = 1; k1 < 32; ++k1) {
+      const float2 t = tw_lds[k1 * 64 + lane];
+      const float ur = __builtin_fmaf(re[k1], t.x, -im[k1] * t.y);
+      const float ui = __builtin_fmaf(re[k1], t.y, im[k1] * t.x);
+      re[k1] = ur;
+      im[k1] = ui;
+    }
+    // transpose: lane l, register k1 -> lane k1 + 32*hb, register m = y[m + 32*hb] of row k1 (natural order in m)
+    const int k1r = lane & 31, hb = lane >> 5;
+#pragma unroll
+    for (int k1 = 0; k1 < 32; ++k1) plane[k1 * kPlaneStride + lane] = re[k1];
+    wave_sync();
+    {
+      const float4* row = reinterpret_cast<const float4*>(plane + k1r * kPlaneStride + 32 * hb);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float4 v = row[j];
+        re[4 * j] = v.x; re[4 * j + 1] = v.y; re[4 * j + 2] = v.z; re[4 * j + 3] = v.w;
+      }
+    }
+    wave_sync();
+#pragma unroll
+    for (int k1 = 0; k1 < 32; ++k1) plane[k1 * kPlaneStride + lane] = im[k1];
+    wave_sync();
+    {
+      const float4* row = reinterpret_cast<const float4*>(plane + k1r * kPlaneStride + 32 * hb);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float4 v = row[j];
+        im[4 * j] = v.x; im[4 * j + 1] = v.y; im[4 * j + 2] = v.z; im[4 * j + 3] = v.w;
+      }
+    }
+    wave_sync();
+    // Radix-2 stage across the lane pair (k1, k1 + 32).  Round 1: registers m and m + 16 trade halves, so the lower
+    // lane holds y[m] (in re[m]) and y[m + 32] (in re[m + 16]) for m < 16 and the upper lane the same for
+    // m' = m + 16; sums and differences are taken in place.  Round 2: the sum register m and the difference register
+    // m + 16 trade halves again: the lower lane ends with all 32 differences, the upper lane with all 32 sums,
+    // each as [values m < 16 | values m >= 16] = natural order.
+#pragma unroll
+    for (int m = 0; m < 16; ++m) {
+      swap32(re[m], re[m + 16]);
+      swap32(im[m], im[m + 16]);
+      const float sr = re[m] + re[m + 16], si = im[m] + im[m + 16];
+      const float dr = re[m] - re[m + 16], di = im[m] - im[m + 16];
+      re[m] = dr; im[m] = di;             // differences where the lower lanes will keep them
+      re[m + 16] = sr; im[m + 16] = si;
+      swap32(re[m], re[m + 16]);
+      swap32(im[m], im[m + 16]);
+      // lower lane: re[m] = d (own m), re[m+16] = d (the upper lane's m, i.e. index m + 16)
+      // upper lane: re[m] = s (the lower lane's m), re[m+16] = s (own m, i.e. index m + 16)
+    }
+    if (hb == 0) {  // the differences take the factor W_64^m before their 32-point transform
+#pragma unroll
+      for (int m = 1; m < 32; ++m) {
+        const float C = kC64[m], S = kS64[m];  // W_64^m = (C, -S)
+        const float ur = __builtin_fmaf(re[m], C, im[m] * S);
+        const float ui = __builtin_fmaf(im[m], C, -re[m] * S);
+        re[m] = ur;
+        im[m] = ui;
+      }
+    }
+    {  // the 32-point network wants its input in bit-reversed register order
+      float tr[32], ti[32];
+#pragma unroll
+      for (int m = 0; m < 32; ++m) { tr[brev5(m)] = re[m]; ti[brev5(m)] = im[m]; }
+#pragma unroll
+      for (int m = 0; m < 32; ++m) { re[m] = tr[m]; im[m] = ti[m]; }
+    }
+    fft32(re, im);  // register k2: Z[k1 + 32*(2*k2 + par)], par = 1 in the lower lanes (differences), 0 in the upper
+
+    // Epilogue in two halves of 512 bins.  With kappa = k1 + 32*par a lane's register k2 is Z[kappa + 64*k2]: registers
+    // 8P..8P+7 go to cell k - 512P, and the partners Z[2048 - 512P - j], j = 1..512, sit in registers 24-8P..31-8P
+    // (j = 512 - kappa - 64*r for register 24-8P+r); j = 0 is one register off: Z[0] (register 0, kappa = 0) in half 0,
+    // Z[1536] (register 24, kappa = 0) in half 1.
+    int le = lane;
+    asm volatile("" : "+v"(le));  // (keeps loop-invariant epilogue addresses out of registers the transforms need)
+    const int kappa = (le & 31) + ((le >> 5) ? 0 : 32);
+    float best_a = -1.0f, best_b = -1.0f;  // FEAT: largest |X|^2 so far and its bin
+    int kbest_a = (int)p.bin_lo, kbest_b = (int)p.bin_lo;
+    const uint64_t row_a = (p.col0 + fb) * p.out_bins, row_b = row_a + p.out_bins;
+    const bool st_a = fb >= f0, st_b = true;  // fb + 1 < nframes always; frame fb belongs to this wavefront unless shifted
+#pragma unroll
+    for (int P = 0; P < 2; ++P) {
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        cell[kappa + 64 * r] = make_float2(re[8 * P + r], im[8 * P + r]);
+        cell[kMirrorBase + 512 - kappa - 64 * r] = make_float2(re[24 - 8 * P + r], im[24 - 8 * P + r]);
+      }
+      if (kappa == 0) cell[kMirrorBase] = P ? make_float2(re[24], im[24]) : make_float2(re[0], im[0]);
+      wave_sync();
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int j4 = 4 * (le + 64 * q);
+        const int k = 512 * P + j4;
+        const float4 z01 = *reinterpret_cast<const float4*>(cell + j4);
+        const float4 z23 = *reinterpret_cast<const float4*>(cell + j4 + 2);
+        const float4 q01 = *reinterpret_cast<const float4*>(cell + kMirrorBase + j4);
+        const float4 q23 = *reinterpret_cast<const float4*>(cell + kMirrorBase + j4 + 2);
+        uint32_t wa = 0, wb = 0;
+        const bool in_band = k >= (int)p.bin_lo && k < (int)p.bin_hi;
+#define SONO_BIN(B, ZR, ZI, PR, PI)                                          \
+  {                                                                          \
+    const float ar = (ZR) + (PR), ai = (ZI) - (PI);                          \
+    const float br = (ZI) + (PI), bi = (PR) - (ZR);                          \
+    const float ma = __builtin_fmaf(ar, ar, ai * ai);                        \
+    const float mb = __builtin_fmaf(br, br, bi * bi);                        \
+    if constexpr (FEAT) { /* a lane visits its bins in ascending order */    \
+      if (in_band && ma > best_a) { best_a = ma; kbest_a = k + B; }          \
+      if (in_band && mb > best_b) { best_b = mb; kbest_b = k + B; }          \
+    } else {                                                                 \
+      wa = put_index<PLUGIN, B>(ma, fs, wa);                                 \
+      wb = put_index<PLUGIN, B>(mb, fs, wb);                                 \
+    }                                                                        \
+  }
+        SONO_BIN(0, z01.x, z01.y, q01.x, q01.y)
+        SONO_BIN(1, z01.z, z01.w, q01.z, q01.w)
+        SONO_BIN(2, z23.x, z23.y, q23.x, q23.y)
+        SONO_BIN(3, z23.z, z23.w, q23.z, q23.w)
+#undef SONO_BIN
+        if (!FEAT && in_band) {
+          const uint32_t col = k - p.out_bin0;
+          if (st_a) *reinterpret_cast<uint32_t*>(out + row_a + col) = wa;
+          if (st_b) *reinterpret_cast<uint32_t*>(out + row_b + col) = wb;
+        }
+      }
+      wave_sync();  // the buffer is rewritten by the next half / the next iteration's transpose
+    }
+    if constexpr (FEAT) {
+      // larger |X|^2 wins, equal values go to the lower bin
+#pragma unroll
+      for (int m = 1; m < 64; m <<= 1) {
+        const float oa = __shfl_xor(best_a, m, 64), ob = __shfl_xor(best_b, m, 64);
+        const int ka = __shfl_xor(kbest_a, m, 64), kb = __shfl_xor(kbest_b, m, 64);
+        if (oa > best_a || (oa == best_a && ka < kbest_a)) { best_a = oa; kbest_a = ka; }
+        if (ob > best_b || (ob == best_b && kb < kbest_b)) { best_b = ob; kbest_b = kb; }
+      }
+      if (lane == 0) {
+        sono_frame_feature* ft = reinterpret_cast<sono_frame_feature*>(p.out) + (p.col0 + fb);
+        if (st_a) {
+          sono_frame_feature r{};
+          r.peak_bin = kbest_a;
+          r.peak_idx = (uint8_t)put_index<PLUGIN, 0>(best_a, fs, 0);
+          ft[0] = r;
+        }
+        sono_frame_feature r{};
+        r.peak_bin = kbest_b;
+        r.peak_idx = (uint8_t)put_index<PLUGIN, 0>(best_b, fs, 0);
+        ft[1] = r;
+      }
+    }
+  }
+}
+
+}  // namespace fast2048
+
+// W_2048^(l*k1) as [k1][l] float2 (cos, -sin), k1 < 32, l < 64, computed in double.
+void build_fast_table_2048(std::vector<float>& t) {
+  t.resize(2 * 2048);
+  const double pi = 3.141592653589793;
+  for (int k1 = 0; k1 < 32; ++k1)
+    for (int l = 0; l < 64; ++l) {
+      const double ang = -2.0 * pi * (double)(k1 * l) / 2048.0;
+      t[2 * (k1 * 64 + l)] = (float)std::cos(ang);
+      t[2 * (k1 * 64 + l) + 1] = (float)std::sin(ang);
+    }
+}
+
+bool fast2048_available(const StftParams& p) {
+  if (p.n != 2048 || p.fast_mode != 1 || !p.fast_table || p.nframes < 2) return false;
+  if ((p.bin_lo & 3) || (p.bin_hi & 3) || p.bin_lo >= p.bin_hi) return false;
+  if (p.out_kind == SONO_OUT_FEATURES) return true;
+  if (p.out_kind != SONO_OUT_U8_INDEX) return false;
+  return !(p.out_bins & 3) && !(p.out_bin0 & 3) && !(reinterpret_cast<uintptr_t>(p.out) & 3);
+}
+
+// Returns 1 if this launch is not served here.
+int launch_stft_fast2048(const StftParams& p, void* stream_v) {
+  using namespace fast2048;
+  if (!fast2048_available(p)) return 1;
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_v);
+  FastScale fs = make_fast_scale(p.scale_mode, p.n, p.gain_db, p.range_db);
+  fs.b -= 2.0f * fs.a;  // the pair separation leaves 2*X: |2X|^2 = 4|X|^2
+  int dev = 0, cus = 256;
+  hipDeviceProp_t prop;
+  if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+    cus = prop.multiProcessorCount;
+  const uint64_t nunits = (p.nframes + 1) / 2;
+  const uint64_t need = (nunits + kWaves - 1) / kWaves;
+  const uint32_t grid = (uint32_t)(need < (uint64_t)cus ? need : (uint64_t)cus);  // persistent: one workgroup per CU
+  const float2* table = reinterpret_cast<const float2*>(p.fast_table);
+  const bool plugin = p.scale_mode == SONO_SCALE_PLUGIN_DB, i16 = p.in_kind == SONO_IN_I16, feat = p.out_kind == SONO_OUT_FEATURES;
+#define SONO_L2048(PL, In, FE, H)                                                                               \
+  do {                                                                                                          \
+    auto kern = stft2048_kernel<PL, In, FE, H>;                                                                 \
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,    \
+                            kLdsBytes) != hipSuccess)                                                           \
+      return SONO_ERR_DEVICE;                                                                                   \
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kWaves * 64), kLdsBytes, stream, p, fs, table);                   \
+  } while (0)
+#define SONO_L2048_F(PL, In)                                                                                   \
+  do {                                                                                                         \
+    if (p.hop == 512) { if (feat) SONO_L2048(PL, In, true, 8); else SONO_L2048(PL, In, false, 8); }             \
+    else { if (feat) SONO_L2048(PL, In, true, 0); else SONO_L2048(PL, In, false, 0); }                          \
+  } while (0)
+  if (plugin) { if (i16) SONO_L2048_F(true, int16_t); else SONO_L2048_F(true, float); }
+  else { if (i16) SONO_L2048_F(false, int16_t); else SONO_L2048_F(false, float); }
+#undef SONO_L2048_F
+#undef SONO_L2048
+  return hipGetLastError() == hipSuccess ? SONO_OK : SONO_ERR_DEVICE;
+}
+
+}  // namespace sono

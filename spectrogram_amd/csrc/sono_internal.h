@@ -58,6 +58,9 @@ void build_fast_table_1024(std::vector<float>& t);
 // build_fast_table_512); colour indices and per-frame peaks.  Returns 1 if it does not serve this launch.
 int launch_stft_fast512(const StftParams& p, void* hip_stream);
 void build_fast_table_512(std::vector<float>& t);
+// kernels_fast2048.hip: the same for 2048-point frames (one complex transform per wavefront), exact roots only.
+int launch_stft_fast2048(const StftParams& p, void* hip_stream);
+void build_fast_table_2048(std::vector<float>& t);
 // kernels_mw.hip: float32 kernel for 2048- and 4096-point frames with the context's twiddle table
 // (returns 1 if it does not serve this size / layout).
 int launch_stft_mw(const StftParams& p, void* hip_stream);

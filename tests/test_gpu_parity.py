@@ -733,13 +733,13 @@ def test_float_and_feature_outputs_at_other_sizes(n):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("hop", [128, 100])
-def test_fast_512_kernel_tails_bands_and_int16(hop):
-    """512-point worker frames (the page's default size) run two transforms per half-wavefront; blocks of eight
-    frames are shifted back at the end of the recording, so every frame count from 8 to 24 is checked, with a
-    band, int16 samples and per-frame peaks, against the checker (colour indices within 1 LSB)."""
+@pytest.mark.parametrize("n,hop", [(512, 128), (512, 100), (2048, 512), (2048, 300)])
+def test_fast_512_and_2048_kernels_tails_bands_and_int16(n, hop):
+    """512-point worker frames (the page's default size) run two transforms per half-wavefront, 2048-point frames
+    one per wavefront; blocks of frames are shifted back at the end of the recording, so every frame count from
+    8 to 24 is checked, with a band, int16 samples and per-frame peaks, against the checker (colour indices
+    within 1 LSB)."""
     rng = np.random.default_rng(3)
-    n = 512
     for frames in list(range(8, 25)) + [131]:
         L = n + hop * (frames - 1)
         x = (rng.standard_normal(L) * 0.08).astype(np.float32)
@@ -751,17 +751,17 @@ def test_fast_512_kernel_tails_bands_and_int16(hop):
         d = np.abs(got.astype(np.int16) - wi)
         assert d.max() <= 1 and (d != 0).mean() < 0.02, (frames, d.max())
         if frames in (8, 13, 24, 131):
-            with worker_engine(n, hop, F.ARITH_FAST_F32, out_kind=F.OUT_U8_INDEX, bin_lo=20, bin_hi=200) as eng:
-                assert np.array_equal(eng.stft(x), got[:, 20:200])
+            with worker_engine(n, hop, F.ARITH_FAST_F32, out_kind=F.OUT_U8_INDEX, bin_lo=20, bin_hi=n // 4 + 72) as eng:
+                assert np.array_equal(eng.stft(x), got[:, 20:n // 4 + 72])
             q = np.round(x * 32767).astype(np.int16)
             xf = (q.astype(np.float32) / 32768).astype(np.float32)
             _, wi16 = oracle.worker_magnitudes(xf, n, hop, frames)
             with worker_engine(n, hop, F.ARITH_FAST_F32, out_kind=F.OUT_U8_INDEX, in_kind=F.IN_I16) as eng:
                 d16 = np.abs(eng.stft(q).astype(np.int16) - wi16)
             assert d16.max() <= 1
-            with worker_engine(n, hop, F.ARITH_FAST_F32, out_kind=F.OUT_FEATURES, bin_lo=4, bin_hi=252) as eng:
+            with worker_engine(n, hop, F.ARITH_FAST_F32, out_kind=F.OUT_FEATURES, bin_lo=4, bin_hi=n // 2 - 4) as eng:
                 ft = eng.stft(x)
-            ref = oracle.frame_peaks_f32(wm, 4, 252)
+            ref = oracle.frame_peaks_f32(wm, 4, n // 2 - 4)
             bad = np.nonzero(ft["peak_bin"] != ref)[0]
             for f in bad:                                        # only near-ties may move
                 assert abs(wm[f, ref[f]] - wm[f, ft["peak_bin"][f]]) <= 2e-5 * wm[f, ref[f]]
