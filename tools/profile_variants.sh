@@ -17,6 +17,7 @@ run() {
 run plugin_u8_1024 600 5 u8 1024 256 plugin
 run plugin_features_1024 600 5 feat 1024 256 plugin
 run worker_u8_512 600 5 u8 512 128 worker
+run worker_u8_2048 600 5 u8 2048 512 worker
 run plugin_u8_2048 600 5 u8 2048 512 plugin
 run plugin_u8_4096 600 5 u8 4096 256 plugin
 run plugin_rgba_4096_crop 60 5 rgba 4096 256 plugin 160 1280
