@@ -25,7 +25,7 @@
 namespace sono {
 namespace fast2048 {
 
-constexpr int kWaves = 15;                          // wavefronts per workgroup (one workgroup per CU): 30 frames per iteration
+constexpr int kWaves = 16;                          // wavefronts per workgroup (one workgroup per CU): 32 frames per iteration
 constexpr int kPlaneStride = 68;                    // floats per transpose row (64 + 4: rows stay 16-B aligned)
 constexpr int kBufBytes = 32 * kPlaneStride * 4;    // 8704 per wavefront
 constexpr int kMirrorBase = 512;                    // epilogue, float2 cells: Z[512P + j] at j, Z[2048 - 512P - j] at 512 + j (j <= 512)
