@@ -21,6 +21,7 @@
 
 #include "sono_device.h"
 #include "sono_internal.h"
+#include "sono_rgba_flush.h"
 
 namespace sono {
 namespace fast512 {
@@ -143,6 +144,76 @@ __device__ __forceinline__ uint32_t put_index(float msq, const FastScale& fs, ui
   }
 }
 
+// Windowed samples (frames A0, A1 as re/im of registers 0..15, B0, B1 of 16..31; lane l = samples 32a + l) to the
+// two spectra: register k2 = Z_g[k1 + 16*k2] in lane 16g + k1.
+template <bool TABLE>
+__device__ __forceinline__ void transform512(float (&re)[32], float (&im)[32], const float2* tw_lds,
+                                             const float2* __restrict__ tw_flat, float* plane, int l) {
+  if constexpr (TABLE) {
+    dit32_table<4, true>(re, im, [&](int half, int j) { return tw_flat[half - 1 + j]; });  // stages T = 1..8, wave-uniform
+  } else {
+    dit32<4>(re, im);  // Y_l[k1] of A in registers k1, of B in 16 + k1
+#pragma unroll
+    for (int r = 0; r < 32; ++r) {
+      if ((r & 15) == 0) continue;
+      const float2 t = tw_lds[(r & 15) * 32 + l];
+      const float ur = __builtin_fmaf(re[r], t.x, -im[r] * t.y);
+      const float ui = __builtin_fmaf(re[r], t.y, im[r] * t.x);
+      re[r] = ur;
+      im[r] = ui;
+    }
+  }
+  // transpose lane l, register r -> lane r, register l; the planes go through one buffer one after the other
+#pragma unroll
+  for (int r = 0; r < 32; ++r) plane[r * kPlaneStride + l] = re[r];
+  wave_sync();
+  {
+    const float4* row = reinterpret_cast<const float4*>(plane + l * kPlaneStride);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float4 v = row[j];
+      re[brev5(4 * j)] = v.x; re[brev5(4 * j + 1)] = v.y; re[brev5(4 * j + 2)] = v.z; re[brev5(4 * j + 3)] = v.w;
+    }
+  }
+  wave_sync();
+#pragma unroll
+  for (int r = 0; r < 32; ++r) plane[r * kPlaneStride + l] = im[r];
+  wave_sync();
+  {
+    const float4* row = reinterpret_cast<const float4*>(plane + l * kPlaneStride);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float4 v = row[j];
+      im[brev5(4 * j)] = v.x; im[brev5(4 * j + 1)] = v.y; im[brev5(4 * j + 2)] = v.z; im[brev5(4 * j + 3)] = v.w;
+    }
+  }
+  wave_sync();
+  if constexpr (TABLE) {
+    int kt = l & 15;
+    asm volatile("" : "+v"(kt));  // (keeps the 31 factor addresses out of registers across the loop)
+    dit32_table<5, false>(re, im, [&](int half, int j) { return tw_lds[(half - 1 + j) * 16 + kt]; });  // stages T = 16..256
+  } else {
+    dit32<5>(re, im);  // register k2 = Z_g[k1 + 16*k2] in lane 16g + k1
+  }
+}
+
+// Half P of the epilogue: lane 16g + k1 lays its Z_g[k], 128P <= k < 128P + 128 (registers 8P..8P+7), out at cell
+// g*128 + (k - 128P) and the partners Z_g[512 - j], j = 128P..128P+128, at kMirrorBase + g*kMirrorStride + (j - 128P):
+// they sit in registers 24-8P..31-8P (cell 128 - k1 - 16r for register 24-8P+r); the ends of that range are one
+// register off: j = 0 is Z[0] (register 0 of lane k1 = 0) and j = 128 of half 1 is Z[384] (register 24 of lane k1 = 0).
+// (P folds to a constant where the caller's loop over P is unrolled)
+__device__ __forceinline__ void epilogue_cells(int P, const float (&re)[32], const float (&im)[32], float2* cell, int le) {
+  const int ge = le >> 4, ke = le & 15;
+  float2* lz = cell + ge * 128;
+  float2* mz = cell + kMirrorBase + ge * kMirrorStride;
+#pragma unroll
+  for (int r = 0; r < 8; ++r) {
+    lz[ke + 16 * r] = make_float2(re[8 * P + r], im[8 * P + r]);
+    mz[128 - ke - 16 * r] = make_float2(re[24 - 8 * P + r], im[24 - 8 * P + r]);
+  }
+  if (ke == 0) mz[0] = P ? make_float2(re[24], im[24]) : make_float2(re[0], im[0]);
+}
+
 // TABLE: the context's per-stage twiddle table (flat layout, the stage with half size T at [T-1, 2T-1)) instead of
 // exact roots.  Lane l's registers are the 16 consecutive bit-reversed positions 16*brev5(l) + brev4(a), so the
 // first pass is the reference's stages T = 1..8 (factors wave-uniform) and, after the transpose, the second pass its
@@ -218,52 +289,7 @@ __global__ __launch_bounds__(kWaves * 64) void stft512_kernel(StftParams p, Fast
         }
       }
     }
-    if constexpr (TABLE) {
-      dit32_table<4, true>(re, im, [&](int half, int j) { return tw_flat[half - 1 + j]; });  // stages T = 1..8, wave-uniform
-    } else {
-      dit32<4>(re, im);  // Y_l[k1] of A in registers k1, of B in 16 + k1
-#pragma unroll
-      for (int r = 0; r < 32; ++r) {
-        if ((r & 15) == 0) continue;
-        const float2 t = tw_lds[(r & 15) * 32 + l];
-        const float ur = __builtin_fmaf(re[r], t.x, -im[r] * t.y);
-        const float ui = __builtin_fmaf(re[r], t.y, im[r] * t.x);
-        re[r] = ur;
-        im[r] = ui;
-      }
-    }
-    // transpose lane l, register r -> lane r, register l; the planes go through one buffer one after the other
-#pragma unroll
-    for (int r = 0; r < 32; ++r) plane[r * kPlaneStride + l] = re[r];
-    wave_sync();
-    {
-      const float4* row = reinterpret_cast<const float4*>(plane + l * kPlaneStride);
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const float4 v = row[j];
-        re[brev5(4 * j)] = v.x; re[brev5(4 * j + 1)] = v.y; re[brev5(4 * j + 2)] = v.z; re[brev5(4 * j + 3)] = v.w;
-      }
-    }
-    wave_sync();
-#pragma unroll
-    for (int r = 0; r < 32; ++r) plane[r * kPlaneStride + l] = im[r];
-    wave_sync();
-    {
-      const float4* row = reinterpret_cast<const float4*>(plane + l * kPlaneStride);
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const float4 v = row[j];
-        im[brev5(4 * j)] = v.x; im[brev5(4 * j + 1)] = v.y; im[brev5(4 * j + 2)] = v.z; im[brev5(4 * j + 3)] = v.w;
-      }
-    }
-    wave_sync();
-    if constexpr (TABLE) {
-      int kt = l & 15;
-      asm volatile("" : "+v"(kt));  // (keeps the 31 factor addresses out of registers across the loop)
-      dit32_table<5, false>(re, im, [&](int half, int j) { return tw_lds[(half - 1 + j) * 16 + kt]; });  // stages T = 16..256
-    } else {
-      dit32<5>(re, im);  // register k2 = Z_g[k1 + 16*k2] in lane 16g + k1
-    }
+    transform512<TABLE>(re, im, tw_lds, tw_flat, plane, l);
 
     // Epilogue in two halves of 128 bins.  After the transpose lane 16g + k1 holds Z_g[k1 + 16*k2] in register k2: for half P the
     // registers 8P..8P+7 go to cell g*128 + (k - 128P), and the partners Z_g[512 - j], j = 128P..128P+128, sit in
@@ -277,16 +303,7 @@ __global__ __launch_bounds__(kWaves * 64) void stft512_kernel(StftParams p, Fast
     int kbest[4] = {(int)p.bin_lo, (int)p.bin_lo, (int)p.bin_lo, (int)p.bin_lo};
 #pragma unroll
     for (int P = 0; P < 2; ++P) {
-      const int ge = le >> 4, ke = le & 15;
-      float2* lz = cell + ge * 128;
-      float2* mz = cell + kMirrorBase + ge * kMirrorStride;
-#pragma unroll
-      for (int r = 0; r < 8; ++r) {
-        lz[ke + 16 * r] = make_float2(re[8 * P + r], im[8 * P + r]);
-        // register 24 - 8P + r: Z[256 + k1 + 16*(8 - 8P + r)], j = 128 + 128P - k1 - 16r, cell j - 128P
-        mz[128 - ke - 16 * r] = make_float2(re[24 - 8 * P + r], im[24 - 8 * P + r]);
-      }
-      if (ke == 0) mz[0] = P ? make_float2(re[24], im[24]) : make_float2(re[0], im[0]);
+      epilogue_cells(P, re, im, cell, le);
       wave_sync();
 #pragma unroll
       for (int q = 0; q < 2; ++q) {  // transform q, bins 128P + 4l .. +3
@@ -350,6 +367,177 @@ __global__ __launch_bounds__(kWaves * 64) void stft512_kernel(StftParams p, Fast
   }
 }
 
+// RGBA: the image [row = row_of_bin0 - bin][column = col0 + frame] of LUT colours instead of [frame][bin] indices,
+// with the slot mechanism of the 1024-point kernel (sono_rgba_flush.h): a workgroup round is 256 consecutive frames =
+// two iterations (a wavefront takes 8 frames per iteration: frame groups 32i + 2*wave + h); the lane that reads the
+// bin quad 32P + l of both transforms already holds four bins x four frames, one 16-byte slot store; one barrier per
+// round; during the next round the first eight wavefronts (256 bins = 8 x 32 image rows) write the finished round
+// out, two quarters per iteration.  The samples of an iteration and the slot reads of its quarters are issued at
+// the end of the iteration before, so that the only wait on the memory counter comes before the image stores.
+// At the end of the recording a block of four frames is shifted back (loads stay in bounds) and the lane moves
+// the frames it owns to the front of its slot cell.
+template <bool PLUGIN, typename In, int HOP32, bool TABLE>
+__global__ __launch_bounds__(kWaves * 64) void stft512_rgba_kernel(StftParams p, FastScale fs, const float2* __restrict__ tw_table,
+                                                                   uint8_t* __restrict__ tiles) {
+  using rgba_flush::kRoundBytes;
+  using rgba_flush::kRoundFrames;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float2* tw_lds = reinterpret_cast<float2*>(smem);
+  float* win_lds = reinterpret_cast<float*>(smem + kTwBytes);
+  uint32_t* lut_lds = reinterpret_cast<uint32_t*>(smem + kLdsBytes);
+  const float2* __restrict__ tw_flat = reinterpret_cast<const float2*>(p.twiddles);
+  for (int i = threadIdx.x; i < 512; i += kWaves * 64) {
+    if constexpr (TABLE) {
+      const int r = i >> 4, kk = i & 15;
+      if (r < 31) {
+        const int t = 1 << (31 - __builtin_clz(r + 1)), j = r + 1 - t;
+        tw_lds[i] = tw_flat[16 * t - 1 + 16 * j + kk];
+      }
+    } else {
+      tw_lds[i] = tw_table[i];
+    }
+    win_lds[(i & 31) * kWinStride + (i >> 5)] = p.window[i];
+  }
+  for (int i = threadIdx.x; i < 256; i += kWaves * 64) lut_lds[i] = p.lut[i];
+  __syncthreads();
+
+  const int lane = threadIdx.x & 63, l = lane & 31, h = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  unsigned char* fbuf = smem + kTwBytes + kWinBytes + (wave * 2 + h) * kFftBufBytes;
+  float* plane = reinterpret_cast<float*>(fbuf);
+  float2* cell = reinterpret_cast<float2*>(fbuf);
+  const float4* win_row = reinterpret_cast<const float4*>(win_lds + l * kWinStride);
+  const In* __restrict__ x = reinterpret_cast<const In*>(p.pcm);
+  const uint32_t per = gridDim.x >> 3;
+  const uint32_t vb = (gridDim.x & 7) ? blockIdx.x : (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+  uint32_t* slots = reinterpret_cast<uint32_t*>(tiles + (size_t)blockIdx.x * 2 * kRoundBytes);
+  // every workgroup runs the same number of rounds and every wavefront goes through every round (barriers)
+  const uint64_t nrounds = (p.nframes + kRoundFrames - 1) / kRoundFrames;
+  const uint64_t rounds = (nrounds + gridDim.x - 1) / gridDim.x;
+
+  // first frame of this half-wavefront in iteration `it` (>= nframes: nothing of its own)
+  auto first_frame = [&](uint64_t it) -> uint64_t {
+    const uint64_t round = it >> 1;
+    if (round >= rounds) return p.nframes;
+    return (round * gridDim.x + vb) * kRoundFrames + 128 * (it & 1) + 8 * wave + 4 * h;
+  };
+  constexpr int kRaw = HOP32 > 0 ? 16 + 3 * HOP32 : 64;
+  float raw[kRaw];
+  auto fetch = [&](uint64_t f0) {  // the block fb .. fb+3 that holds this half's frames, shifted back at the end
+    const uint64_t fb = f0 + 4 <= p.nframes ? f0 : p.nframes - 4;
+    const In* x0 = x + (p.frame0 + fb) * p.hop + l;
+    if constexpr (HOP32 > 0) {
+#pragma unroll
+      for (int a = 0; a < kRaw; ++a) raw[a] = ld<In>(x0, 32 * a);
+    } else {
+      const In *x1 = x0 + p.hop, *x2 = x1 + p.hop, *x3 = x2 + p.hop;
+#pragma unroll
+      for (int a = 0; a < 16; ++a) {
+        raw[a] = ld<In>(x0, 32 * a);
+        raw[16 + a] = ld<In>(x1, 32 * a);
+        raw[32 + a] = ld<In>(x2, 32 * a);
+        raw[48 + a] = ld<In>(x3, 32 * a);
+      }
+    }
+  };
+  fetch(first_frame(0));
+  uint4 fqa[2] = {}, fqb[2] = {};  // slot reads of the two quarters the iteration writes out
+  for (uint64_t it = 0; it < (rounds + 1) * 2; ++it) {
+    const uint64_t round = it >> 1;
+    const int i = (int)(it & 1);
+    const uint64_t f0 = first_frame(it);
+    uint32_t* slot = slots + (round & 1) * (kRoundBytes / 4);
+    // (the empty asm is a use of the loaded registers: the wait for them lands here, before the image stores)
+#pragma unroll
+    for (int a = 0; a < kRaw; ++a) asm volatile("" : "+v"(raw[a]));
+    if (round > 0) {
+      const uint64_t frame0 = ((round - 1) * gridDim.x + vb) * kRoundFrames;
+      if (frame0 < p.nframes) {
+        rgba_flush::flush_quarter_store(p, fqa, lut_lds, frame0, 2 * i, wave, lane);
+        rgba_flush::flush_quarter_store(p, fqb, lut_lds, frame0, 2 * i + 1, wave, lane);
+      }
+    }
+    // wave-uniform: does this wavefront have a frame in this iteration?
+    const uint64_t wave_f0 = round < rounds ? (round * gridDim.x + vb) * kRoundFrames + 128 * i + 8 * wave : p.nframes;
+    if (wave_f0 < p.nframes) {
+      float re[32], im[32];
+      {
+        float win[16];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float4 v = win_row[j];
+          win[4 * j] = v.x; win[4 * j + 1] = v.y; win[4 * j + 2] = v.z; win[4 * j + 3] = v.w;
+        }
+#pragma unroll
+        for (int a = 0; a < 16; ++a) {
+          re[brev4(a)] = raw[a] * win[a];
+          im[brev4(a)] = raw[a + (HOP32 > 0 ? HOP32 : 16)] * win[a];
+          re[16 + brev4(a)] = raw[a + (HOP32 > 0 ? 2 * HOP32 : 32)] * win[a];
+          im[16 + brev4(a)] = raw[a + (HOP32 > 0 ? 3 * HOP32 : 48)] * win[a];
+        }
+      }
+      transform512<TABLE>(re, im, tw_lds, tw_flat, plane, l);
+
+      int lane_e = lane;
+      asm volatile("" : "+v"(lane_e));  // (keeps loop-invariant addresses out of registers the transforms need)
+      const int le = lane_e & 31, he = lane_e >> 5;
+      // frames of this lane's slot cell: f0 .. f0+3; the block computed is fb = f0 - shift .. (shift > 0 at the end)
+      const uint64_t fb = f0 + 4 <= p.nframes ? f0 : p.nframes - 4;
+      const int shift = f0 >= p.nframes ? 4 : (int)(f0 - fb);
+      const int fg = 32 * i + 2 * wave + he;
+#pragma unroll
+      for (int P = 0; P < 2; ++P) {
+        epilogue_cells(P, re, im, cell, le);
+        wave_sync();
+        uint32_t w4[4];  // colour indices of bins 128P + 4le .. +3 of the frames fb, fb+1 (transform 0), fb+2, fb+3 (transform 1)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const float2* lr = cell + q * 128 + 4 * le;
+          const float2* mr = cell + kMirrorBase + q * kMirrorStride + 4 * le;
+          const float4 z01 = *reinterpret_cast<const float4*>(lr);
+          const float4 z23 = *reinterpret_cast<const float4*>(lr + 2);
+          const float4 q01 = *reinterpret_cast<const float4*>(mr);
+          const float4 q23 = *reinterpret_cast<const float4*>(mr + 2);
+          uint32_t wa = 0, wb = 0;
+#define SONO_BIN(B, ZR, ZI, PR, PI)                                          \
+  {                                                                          \
+    const float ar = (ZR) + (PR), ai = (ZI) - (PI);                          \
+    const float br = (ZI) + (PI), bi = (PR) - (ZR);                          \
+    wa = put_index<PLUGIN, B>(__builtin_fmaf(ar, ar, ai * ai), fs, wa);      \
+    wb = put_index<PLUGIN, B>(__builtin_fmaf(br, br, bi * bi), fs, wb);      \
+  }
+          SONO_BIN(0, z01.x, z01.y, q01.x, q01.y)
+          SONO_BIN(1, z01.z, z01.w, q01.z, q01.w)
+          SONO_BIN(2, z23.x, z23.y, q23.x, q23.y)
+          SONO_BIN(3, z23.z, z23.w, q23.z, q23.w)
+#undef SONO_BIN
+          w4[2 * q] = wa;
+          w4[2 * q + 1] = wb;
+        }
+        if (shift != 0) {  // the frames this lane owns start at position `shift` of the block
+          const uint32_t c1 = w4[1], c2 = w4[2], c3 = w4[3];
+          w4[0] = shift == 1 ? c1 : shift == 2 ? c2 : c3;
+          w4[1] = shift == 1 ? c2 : c3;
+          w4[2] = c3;
+        }
+        const int kq = 32 * P + le;
+        if (4 * kq >= (int)p.bin_lo && 4 * kq < (int)p.bin_hi)
+          reinterpret_cast<uint4*>(slot)[rgba_flush::slot_cell(kq, fg)] = make_uint4(w4[0], w4[1], w4[2], w4[3]);
+        wave_sync();  // the buffer is rewritten by the next half / the next iteration's transpose
+      }
+    }
+    fetch(first_frame(it + 1));  // unconditional: a half with nothing of its own reads the last block of the recording
+    if (i == 1) __syncthreads();  // this round's slot is complete and everyone is done reading the other one
+    const uint64_t nround = (it + 1) >> 1;
+    if (nround > 0 && nround <= rounds) {
+      const uint32_t* prev = slots + ((nround - 1) & 1) * (kRoundBytes / 4);
+      const int ni = (int)((it + 1) & 1);
+      rgba_flush::flush_quarter_load(fqa, prev, 2 * ni, wave, lane);
+      rgba_flush::flush_quarter_load(fqb, prev, 2 * ni + 1, wave, lane);
+    }
+  }
+}
+
 }  // namespace fast512
 
 // W_512^(l*k1) as [k1][l] float2 (cos, -sin), k1 < 16, l < 32, computed in double.
@@ -373,10 +561,21 @@ bool fast512_available(const StftParams& p) {
   return !(p.out_bins & 3) && !(p.out_bin0 & 3) && !(reinterpret_cast<uintptr_t>(p.out) & 3);
 }
 
+// The image output needs whole 16-bin groups, the flipped full-height row mapping, a LUT and the scratch buffer
+// (fast_rgba_scratch_bytes()).
+bool fast512_rgba_available(const StftParams& p) {
+  if (p.n != 512 || p.nframes < 8) return false;
+  if (!((p.fast_mode == 1 && p.fast_table) || (p.fast_mode == 2 && p.twiddles))) return false;
+  if ((p.bin_lo & 15) || (p.bin_hi & 15) || p.bin_lo >= p.bin_hi) return false;
+  if (p.row_of_bin0 != (int32_t)p.bin_hi - 1) return false;
+  return p.width != 0 && p.width <= ((uint64_t)1 << 24) && p.lut;
+}
+
 // Returns 1 if this launch is not served here.
 int launch_stft_fast512(const StftParams& p, void* stream_v) {
   using namespace fast512;
-  if (!fast512_available(p)) return 1;
+  const bool rgba = p.out_kind == SONO_OUT_RGBA8;
+  if (rgba ? !(fast512_rgba_available(p) && p.tile_scratch) : !fast512_available(p)) return 1;
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_v);
   FastScale fs = make_fast_scale(p.scale_mode, p.n, p.gain_db, p.range_db);
   fs.b -= 2.0f * fs.a;  // the pair separation leaves 2*X: |2X|^2 = 4|X|^2
@@ -390,6 +589,30 @@ int launch_stft_fast512(const StftParams& p, void* stream_v) {
   const float2* table = reinterpret_cast<const float2*>(p.fast_table);
   const bool plugin = p.scale_mode == SONO_SCALE_PLUGIN_DB, i16 = p.in_kind == SONO_IN_I16, feat = p.out_kind == SONO_OUT_FEATURES;
   const bool tab = p.fast_mode == 2;
+  if (rgba) {
+    const uint64_t nr = (p.nframes + rgba_flush::kRoundFrames - 1) / rgba_flush::kRoundFrames;
+    const uint32_t rgrid = (uint32_t)(nr < (uint64_t)cus ? nr : (uint64_t)cus);
+    uint8_t* tiles = reinterpret_cast<uint8_t*>(p.tile_scratch);
+    const int lds = kLdsBytes + rgba_flush::kLutBytes;
+#define SONO_R512(PL, In, H, T)                                                                                 \
+  do {                                                                                                          \
+    auto kern = stft512_rgba_kernel<PL, In, H, T>;                                                              \
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,    \
+                            lds) != hipSuccess)                                                                 \
+      return SONO_ERR_DEVICE;                                                                                   \
+    hipLaunchKernelGGL(kern, dim3(rgrid), dim3(kWaves * 64), lds, stream, p, fs, table, tiles);                 \
+  } while (0)
+#define SONO_R512_H(PL, In)                                                                                    \
+  do {                                                                                                         \
+    if (tab) { if (p.hop == 128) SONO_R512(PL, In, 4, true); else SONO_R512(PL, In, 0, true); }                 \
+    else { if (p.hop == 128) SONO_R512(PL, In, 4, false); else SONO_R512(PL, In, 0, false); }                   \
+  } while (0)
+    if (plugin) { if (i16) SONO_R512_H(true, int16_t); else SONO_R512_H(true, float); }
+    else { if (i16) SONO_R512_H(false, int16_t); else SONO_R512_H(false, float); }
+#undef SONO_R512_H
+#undef SONO_R512
+    return hipGetLastError() == hipSuccess ? SONO_OK : SONO_ERR_DEVICE;
+  }
 #define SONO_L512(PL, In, FE, H, T)                                                                              \
   do {                                                                                                          \
     auto kern = stft512_kernel<PL, In, FE, H, T>;                                                                \

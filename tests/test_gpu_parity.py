@@ -767,3 +767,58 @@ def test_fast_512_and_2048_kernels_tails_bands_and_int16(n, hop):
                 assert abs(wm[f, ref[f]] - wm[f, ft["peak_bin"][f]]) <= 2e-5 * wm[f, ref[f]]
             assert len(ft) == frames and len(bad) <= 1
             assert np.abs(ft["peak_idx"].astype(np.int16) - wi[np.arange(frames), ft["peak_bin"]]).max() <= 1
+
+
+def _image_of_indices(idx, width, lut):
+    """The worker's image from [frame][bin] colour indices: bin b of frame f at row bins-1-b, column f; a frame
+    past the last column wraps to column 0 one row down, its bin 0 falling off (spectrogramWorker.js:40,59,79)."""
+    l4 = lut.reshape(256, 4)
+    img = l4[idx[:width].T[::-1]].copy()
+    for f in range(width, idx.shape[0]):
+        img[1:, 0] = l4[idx[f][1:][::-1]]
+    return img
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("hop", [128, 96])
+def test_fast_512_image_writer_rounds_tails_and_bands(hop):
+    """The 512-point kernel writes the RGBA image itself (rounds of 256 frames per workgroup, written out during
+    the next round): frame counts around the block size (4), the round size (256) and several rounds, with and
+    without the wrapped last frame, a band of 16-bin groups, int16 samples, and the plugin flavour with its own
+    twiddle table; every image must be the colour map applied to the indices the uint8 output of the same
+    arithmetic gives (bit-identical), which the other tests hold to the checker."""
+    n = 512
+    rng = np.random.default_rng(17)
+    lut = (np.arange(1024, dtype=np.uint32) * 11 % 253).astype(np.uint8)
+    for frames in list(range(8, 21)) + [131, 255, 256, 257, 258, 259, 513, 1100, 256 * 300 + 2]:
+        for extra in (0, 37):                                   # 0: (L-N) % hop == 0, one frame more than columns
+            L = n + hop * (frames - 1) + extra
+            x = (rng.standard_normal(L) * 0.1).astype(np.float32)
+            x[L // 3:L // 2] += (0.4 * np.sin(np.arange(L // 2 - L // 3) * 0.7)).astype(np.float32)
+            with worker_engine(n, hop, F.ARITH_FAST_F32, out_kind=F.OUT_U8_INDEX) as e8, \
+                    worker_engine(n, hop, F.ARITH_FAST_F32) as er:
+                er.set_colormap(lut)
+                idx, img = e8.stft(x), er.stft(x)
+                g = er.geometry(L)
+            assert idx.shape[0] == g.frames and g.frames - g.width == (1 if extra == 0 else 0)
+            assert img.shape == (256, g.width, 4)
+            assert np.array_equal(img, _image_of_indices(idx, g.width, lut)), (frames, extra)
+            if frames in (8, 13, 259, 1100):
+                with worker_engine(n, hop, F.ARITH_FAST_F32, bin_lo=32, bin_hi=208) as eb:
+                    eb.set_colormap(lut)
+                    band = eb.stft(x)
+                assert np.array_equal(band, img[256 - 208:256 - 32]), (frames, extra)    # the band is a crop of the image
+                q = np.round(x * 32767).astype(np.int16)
+                with worker_engine(n, hop, F.ARITH_FAST_F32, out_kind=F.OUT_U8_INDEX, in_kind=F.IN_I16) as e8, \
+                        worker_engine(n, hop, F.ARITH_FAST_F32, in_kind=F.IN_I16) as er:
+                    er.set_colormap(lut)
+                    assert np.array_equal(er.stft(q), _image_of_indices(e8.stft(q), g.width, lut))
+    # plugin flavour (recurrence twiddle table, gain/range quantiser): image == colour map of its own indices
+    for frames in (9, 300, 777):
+        L = n + hop * (frames - 1) + 5
+        x = (rng.standard_normal(L) * 0.1).astype(np.float32)
+        with plugin_engine(n, hop, F.ARITH_FAST_F32, out_kind=F.OUT_U8_INDEX) as e8, \
+                plugin_engine(n, hop, F.ARITH_FAST_F32, out_kind=F.OUT_RGBA8) as er:
+            er.set_colormap(lut)
+            idx, img = e8.stft(x), er.stft(x)
+        assert np.array_equal(img, lut.reshape(256, 4)[idx.T[::-1]]), frames
