@@ -387,7 +387,7 @@ int sono_stft_async(sono_ctx* c, const void* pcm, uint64_t L, void* out, uint64_
     int r = 1;
     StftParams qq = q;
     if (!qq.lut) qq.lut = c->d_lut + 256;
-    if (fast_eligible(c) && q.out_kind == SONO_OUT_RGBA8 && (fast_rgba_available(qq) || fast512_rgba_available(qq))) {
+    if (fast_eligible(c) && q.out_kind == SONO_OUT_RGBA8 && (fast_rgba_available(qq) || fast512_rgba_available(qq) || fast2048_rgba_available(qq))) {
       // the fast kernel writes the image itself; it needs a small scratch buffer for its wavefront tiles
       int rc2 = ensure(c, &c->d_aux, &c->d_aux_bytes, fast_rgba_scratch_bytes());
       if (rc2 != SONO_OK) return rc2;
@@ -396,6 +396,7 @@ int sono_stft_async(sono_ctx* c, const void* pcm, uint64_t L, void* out, uint64_
       if (!u.lut) u.lut = c->d_lut + 256;
       r = launch_stft_fast(u, c->stream);
       if (r == 1) r = launch_stft_fast512(u, c->stream);
+      if (r == 1) r = launch_stft_fast2048(u, c->stream);
       if (r != SONO_OK) return fail(c, r, "kernel launch failed: %s", hipGetErrorString(hipGetLastError()));
       return SONO_OK;
     }

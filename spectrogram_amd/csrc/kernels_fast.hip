@@ -560,7 +560,8 @@ static int cu_count() {
   return 256;
 }
 
-uint64_t fast_rgba_scratch_bytes() { return (uint64_t)cu_count() * 2 * fast1024::kRoundBytes; }
+// two slots per workgroup; a slot of the 2048-point kernel (1024 bins x 256 frames) is twice that of the others
+uint64_t fast_rgba_scratch_bytes() { return (uint64_t)cu_count() * 2 * 2 * fast1024::kRoundBytes; }
 
 int launch_stft_fast(const StftParams& p, void* stream_v) {
   using namespace fast1024;

@@ -21,6 +21,7 @@
 
 #include "sono_device.h"
 #include "sono_internal.h"
+#include "sono_rgba_flush.h"
 
 namespace sono {
 namespace fast2048 {
@@ -129,6 +130,95 @@ __device__ __forceinline__ uint32_t put_index(float msq, const FastScale& fs, ui
   }
 }
 
+// The complex 2048-point transform of one wavefront: in, lane l register brev5(a) = z[64a + l]; out, register k2 =
+// Z[k1 + 32*(2*k2 + par)] with k1 = lane & 31 and par = 1 in lanes 0..31 (differences), 0 in lanes 32..63.
+__device__ __forceinline__ void transform2048(float (&re)[32], float (&im)[32], const float2* tw_lds, float* plane, int lane) {
+  fft32(re, im);  // Y_l[k1]
+#pragma unroll
+  for (int k1 = 1; k1 < 32; ++k1) {
+    const float2 t = tw_lds[k1 * 64 + lane];
+    const float ur = __builtin_fmaf(re[k1], t.x, -im[k1] * t.y);
+    const float ui = __builtin_fmaf(re[k1], t.y, im[k1] * t.x);
+    re[k1] = ur;
+    im[k1] = ui;
+  }
+  // transpose: lane l, register k1 -> lane k1 + 32*hb, register m = y[m + 32*hb] of row k1 (natural order in m)
+  const int k1r = lane & 31, hb = lane >> 5;
+#pragma unroll
+  for (int k1 = 0; k1 < 32; ++k1) plane[k1 * kPlaneStride + lane] = re[k1];
+  wave_sync();
+  {
+    const float4* row = reinterpret_cast<const float4*>(plane + k1r * kPlaneStride + 32 * hb);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float4 v = row[j];
+      re[4 * j] = v.x; re[4 * j + 1] = v.y; re[4 * j + 2] = v.z; re[4 * j + 3] = v.w;
+    }
+  }
+  wave_sync();
+#pragma unroll
+  for (int k1 = 0; k1 < 32; ++k1) plane[k1 * kPlaneStride + lane] = im[k1];
+  wave_sync();
+  {
+    const float4* row = reinterpret_cast<const float4*>(plane + k1r * kPlaneStride + 32 * hb);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float4 v = row[j];
+      im[4 * j] = v.x; im[4 * j + 1] = v.y; im[4 * j + 2] = v.z; im[4 * j + 3] = v.w;
+    }
+  }
+  wave_sync();
+  // Radix-2 stage across the lane pair (k1, k1 + 32).  Round 1: registers m and m + 16 trade halves, so the lower
+  // lane holds y[m] (in re[m]) and y[m + 32] (in re[m + 16]) for m < 16 and the upper lane the same for
+  // m' = m + 16; sums and differences are taken in place.  Round 2: the sum register m and the difference register
+  // m + 16 trade halves again: the lower lane ends with all 32 differences, the upper lane with all 32 sums,
+  // each as [values m < 16 | values m >= 16] = natural order.
+#pragma unroll
+  for (int m = 0; m < 16; ++m) {
+    swap32(re[m], re[m + 16]);
+    swap32(im[m], im[m + 16]);
+    const float sr = re[m] + re[m + 16], si = im[m] + im[m + 16];
+    const float dr = re[m] - re[m + 16], di = im[m] - im[m + 16];
+    re[m] = dr; im[m] = di;             // differences where the lower lanes will keep them
+    re[m + 16] = sr; im[m + 16] = si;
+    swap32(re[m], re[m + 16]);
+    swap32(im[m], im[m + 16]);
+    // lower lane: re[m] = d (own m), re[m+16] = d (the upper lane's m, i.e. index m + 16)
+    // upper lane: re[m] = s (the lower lane's m), re[m+16] = s (own m, i.e. index m + 16)
+  }
+  if (hb == 0) {  // the differences take the factor W_64^m before their 32-point transform
+#pragma unroll
+    for (int m = 1; m < 32; ++m) {
+      const float C = kC64[m], S = kS64[m];  // W_64^m = (C, -S)
+      const float ur = __builtin_fmaf(re[m], C, im[m] * S);
+      const float ui = __builtin_fmaf(im[m], C, -re[m] * S);
+      re[m] = ur;
+      im[m] = ui;
+    }
+  }
+  {  // the 32-point network wants its input in bit-reversed register order
+    float tr[32], ti[32];
+#pragma unroll
+    for (int m = 0; m < 32; ++m) { tr[brev5(m)] = re[m]; ti[brev5(m)] = im[m]; }
+#pragma unroll
+    for (int m = 0; m < 32; ++m) { re[m] = tr[m]; im[m] = ti[m]; }
+  }
+  fft32(re, im);  // register k2: Z[k1 + 32*(2*k2 + par)], par = 1 in the lower lanes (differences), 0 in the upper
+}
+
+// Epilogue half P: Z[512P + j] to cell j and the partners Z[2048 - 512P - j] to cell kMirrorBase + j (j <= 512).  With
+// kappa = k1 + 32*par a lane's register k2 is Z[kappa + 64*k2]: registers 8P..8P+7 are the bins, registers 24-8P..31-8P
+// the partners (j = 512 - kappa - 64*r for register 24-8P+r); j = 0 is one register off: Z[0] (register 0, kappa = 0)
+// in half 0, Z[1536] (register 24, kappa = 0) in half 1.
+__device__ __forceinline__ void epilogue_cells(int P, const float (&re)[32], const float (&im)[32], float2* cell, int kappa) {
+#pragma unroll
+  for (int r = 0; r < 8; ++r) {
+    cell[kappa + 64 * r] = make_float2(re[8 * P + r], im[8 * P + r]);
+    cell[kMirrorBase + 512 - kappa - 64 * r] = make_float2(re[24 - 8 * P + r], im[24 - 8 * P + r]);
+  }
+  if (kappa == 0) cell[kMirrorBase] = P ? make_float2(re[24], im[24]) : make_float2(re[0], im[0]);
+}
+
 template <bool PLUGIN, typename In, bool FEAT, int HOP64>
 __global__ __launch_bounds__(kWaves * 64) void stft2048_kernel(StftParams p, FastScale fs, const float2* __restrict__ tw_table) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -180,82 +270,9 @@ __global__ __launch_bounds__(kWaves * 64) void stft2048_kernel(StftParams p, Fas
         }
       }
     }
-    fft32(re, im);  // Y_l[k1]
-#pragma unroll
-    for (int k1 = 1; k1 < 32; ++k1) {
-      const float2 t = tw_lds[k1 * 64 + lane];
-      const float ur = __builtin_fmaf(re[k1], t.x, -im[k1] * t.y);
-      const float ui = __builtin_fmaf(re[k1], t.y, im[k1] * t.x);
-      re[k1] = ur;
-      im[k1] = ui;
-    }
-    // transpose: lane l, register k1 -> lane k1 + 32*hb, register m = y[m + 32*hb] of row k1 (natural order in m)
-    const int k1r = lane & 31, hb = lane >> 5;
-#pragma unroll
-    for (int k1 = 0; k1 < 32; ++k1) plane[k1 * kPlaneStride + lane] = re[k1];
-    wave_sync();
-    {
-      const float4* row = reinterpret_cast<const float4*>(plane + k1r * kPlaneStride + 32 * hb);
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const float4 v = row[j];
-        re[4 * j] = v.x; re[4 * j + 1] = v.y; re[4 * j + 2] = v.z; re[4 * j + 3] = v.w;
-      }
-    }
-    wave_sync();
-#pragma unroll
-    for (int k1 = 0; k1 < 32; ++k1) plane[k1 * kPlaneStride + lane] = im[k1];
-    wave_sync();
-    {
-      const float4* row = reinterpret_cast<const float4*>(plane + k1r * kPlaneStride + 32 * hb);
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const float4 v = row[j];
-        im[4 * j] = v.x; im[4 * j + 1] = v.y; im[4 * j + 2] = v.z; im[4 * j + 3] = v.w;
-      }
-    }
-    wave_sync();
-    // Radix-2 stage across the lane pair (k1, k1 + 32).  Round 1: registers m and m + 16 trade halves, so the lower
-    // lane holds y[m] (in re[m]) and y[m + 32] (in re[m + 16]) for m < 16 and the upper lane the same for
-    // m' = m + 16; sums and differences are taken in place.  Round 2: the sum register m and the difference register
-    // m + 16 trade halves again: the lower lane ends with all 32 differences, the upper lane with all 32 sums,
-    // each as [values m < 16 | values m >= 16] = natural order.
-#pragma unroll
-    for (int m = 0; m < 16; ++m) {
-      swap32(re[m], re[m + 16]);
-      swap32(im[m], im[m + 16]);
-      const float sr = re[m] + re[m + 16], si = im[m] + im[m + 16];
-      const float dr = re[m] - re[m + 16], di = im[m] - im[m + 16];
-      re[m] = dr; im[m] = di;             // differences where the lower lanes will keep them
-      re[m + 16] = sr; im[m + 16] = si;
-      swap32(re[m], re[m + 16]);
-      swap32(im[m], im[m + 16]);
-      // lower lane: re[m] = d (own m), re[m+16] = d (the upper lane's m, i.e. index m + 16)
-      // upper lane: re[m] = s (the lower lane's m), re[m+16] = s (own m, i.e. index m + 16)
-    }
-    if (hb == 0) {  // the differences take the factor W_64^m before their 32-point transform
-#pragma unroll
-      for (int m = 1; m < 32; ++m) {
-        const float C = kC64[m], S = kS64[m];  // W_64^m = (C, -S)
-        const float ur = __builtin_fmaf(re[m], C, im[m] * S);
-        const float ui = __builtin_fmaf(im[m], C, -re[m] * S);
-        re[m] = ur;
-        im[m] = ui;
-      }
-    }
-    {  // the 32-point network wants its input in bit-reversed register order
-      float tr[32], ti[32];
-#pragma unroll
-      for (int m = 0; m < 32; ++m) { tr[brev5(m)] = re[m]; ti[brev5(m)] = im[m]; }
-#pragma unroll
-      for (int m = 0; m < 32; ++m) { re[m] = tr[m]; im[m] = ti[m]; }
-    }
-    fft32(re, im);  // register k2: Z[k1 + 32*(2*k2 + par)], par = 1 in the lower lanes (differences), 0 in the upper
+    transform2048(re, im, tw_lds, plane, lane);
 
-    // Epilogue in two halves of 512 bins.  With kappa = k1 + 32*par a lane's register k2 is Z[kappa + 64*k2]: registers
-    // 8P..8P+7 go to cell k - 512P, and the partners Z[2048 - 512P - j], j = 1..512, sit in registers 24-8P..31-8P
-    // (j = 512 - kappa - 64*r for register 24-8P+r); j = 0 is one register off: Z[0] (register 0, kappa = 0) in half 0,
-    // Z[1536] (register 24, kappa = 0) in half 1.
+    // Epilogue in two halves of 512 bins.
     int le = lane;
     asm volatile("" : "+v"(le));  // (keeps loop-invariant epilogue addresses out of registers the transforms need)
     const int kappa = (le & 31) + ((le >> 5) ? 0 : 32);
@@ -265,12 +282,7 @@ __global__ __launch_bounds__(kWaves * 64) void stft2048_kernel(StftParams p, Fas
     const bool st_a = fb >= f0, st_b = true;  // fb + 1 < nframes always; frame fb belongs to this wavefront unless shifted
 #pragma unroll
     for (int P = 0; P < 2; ++P) {
-#pragma unroll
-      for (int r = 0; r < 8; ++r) {
-        cell[kappa + 64 * r] = make_float2(re[8 * P + r], im[8 * P + r]);
-        cell[kMirrorBase + 512 - kappa - 64 * r] = make_float2(re[24 - 8 * P + r], im[24 - 8 * P + r]);
-      }
-      if (kappa == 0) cell[kMirrorBase] = P ? make_float2(re[24], im[24]) : make_float2(re[0], im[0]);
+      epilogue_cells(P, re, im, cell, kappa);
       wave_sync();
 #pragma unroll
       for (int q = 0; q < 2; ++q) {
@@ -335,6 +347,133 @@ __global__ __launch_bounds__(kWaves * 64) void stft2048_kernel(StftParams p, Fas
   }
 }
 
+// RGBA: the image [row = row_of_bin0 - bin][column = col0 + frame] of LUT colours, with the slot mechanism of the
+// 1024-point kernel (sono_rgba_flush.h).  A workgroup round is 256 consecutive frames = eight iterations of 32 frames
+// (wavefront w: frames 32i + 2w, +1 of the round); a slot holds 1024 bins x 256 frames = 256 KiB as 32 reader units of
+// 32 bins; two wavefronts fill one 16-byte cell (four bins x four frames) with 8 bytes each.  During the next round
+// wavefront w writes out, in iteration i, quarter i & 3 of reader unit w + 16*(i >> 2).  The samples of an iteration
+// and the slot reads of its quarter are issued at the end of the iteration before.  The colour table is read from
+// global memory: the transforms use all of the CU's LDS.
+constexpr int kSlotBytes = 2 * rgba_flush::kRoundBytes;
+
+template <bool PLUGIN, typename In, int HOP64>
+__global__ __launch_bounds__(kWaves * 64) void stft2048_rgba_kernel(StftParams p, FastScale fs, const float2* __restrict__ tw_table,
+                                                                    uint8_t* __restrict__ tiles) {
+  using rgba_flush::kRoundFrames;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float2* tw_lds = reinterpret_cast<float2*>(smem);
+  float* win_lds = reinterpret_cast<float*>(smem + kTwBytes);
+  for (int i = threadIdx.x; i < 2048; i += kWaves * 64) {
+    tw_lds[i] = tw_table[i];
+    win_lds[i] = p.window[i];
+  }
+  __syncthreads();
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  unsigned char* fbuf = smem + kTwBytes + kWinBytes + wave * kBufBytes;
+  float* plane = reinterpret_cast<float*>(fbuf);
+  float2* cell = reinterpret_cast<float2*>(fbuf);
+  const In* __restrict__ x = reinterpret_cast<const In*>(p.pcm);
+  const uint32_t per = gridDim.x >> 3;
+  const uint32_t vb = (gridDim.x & 7) ? blockIdx.x : (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+  uint32_t* slots = reinterpret_cast<uint32_t*>(tiles + (size_t)blockIdx.x * 2 * kSlotBytes);
+  // every workgroup runs the same number of rounds and every wavefront goes through every round (barriers)
+  const uint64_t nrounds = (p.nframes + kRoundFrames - 1) / kRoundFrames;
+  const uint64_t rounds = (nrounds + gridDim.x - 1) / gridDim.x;
+
+  auto first_frame = [&](uint64_t it) -> uint64_t {  // of this wavefront in iteration `it` (>= nframes: none)
+    const uint64_t round = it >> 3;
+    if (round >= rounds) return p.nframes;
+    return (round * gridDim.x + vb) * kRoundFrames + 32 * (it & 7) + 2 * wave;
+  };
+  constexpr int kRaw = HOP64 > 0 ? 32 + HOP64 : 64;
+  float raw[kRaw];
+  auto fetch = [&](uint64_t f0) {  // frames fb, fb + 1 (shifted back by one at an odd end, and to the end when there is nothing to do)
+    const uint64_t fb = f0 + 2 <= p.nframes ? f0 : p.nframes - 2;
+    const In* x0 = x + (p.frame0 + fb) * p.hop + lane;
+    if constexpr (HOP64 > 0) {
+#pragma unroll
+      for (int a = 0; a < kRaw; ++a) raw[a] = ld<In>(x0, 64 * a);
+    } else {
+      const In* x1 = x0 + p.hop;
+#pragma unroll
+      for (int a = 0; a < 32; ++a) {
+        raw[a] = ld<In>(x0, 64 * a);
+        raw[32 + a] = ld<In>(x1, 64 * a);
+      }
+    }
+  };
+  fetch(first_frame(0));
+  uint4 fq[2] = {};
+  for (uint64_t it = 0; it < (rounds + 1) * 8; ++it) {
+    const uint64_t round = it >> 3;
+    const int i = (int)(it & 7);
+    const uint64_t f0 = first_frame(it);
+    uint32_t* slot = slots + (round & 1) * (kSlotBytes / 4);
+    // (the empty asm is a use of the loaded registers: the wait for them lands here, before the image stores)
+#pragma unroll
+    for (int a = 0; a < kRaw; ++a) asm volatile("" : "+v"(raw[a]));
+    if (round > 0) {
+      const uint64_t frame0 = ((round - 1) * gridDim.x + vb) * kRoundFrames;
+      if (frame0 < p.nframes) rgba_flush::flush_quarter_store(p, fq, p.lut, frame0, i & 3, wave + 16 * (i >> 2), lane);
+    }
+    if (f0 < p.nframes) {  // wave-uniform
+      float re[32], im[32];
+#pragma unroll
+      for (int a = 0; a < 32; ++a) {
+        const float w = win_lds[64 * a + lane];
+        re[brev5(a)] = raw[a] * w;
+        im[brev5(a)] = raw[a + (HOP64 > 0 ? HOP64 : 32)] * w;
+      }
+      transform2048(re, im, tw_lds, plane, lane);
+
+      int le = lane;
+      asm volatile("" : "+v"(le));  // (keeps loop-invariant epilogue addresses out of registers the transforms need)
+      const int kappa = (le & 31) + ((le >> 5) ? 0 : 32);
+      const bool shifted = f0 + 2 > p.nframes;  // odd end: frame f0 is the second of the pair transformed
+      const int fg = 8 * i + (wave >> 1);
+#pragma unroll
+      for (int P = 0; P < 2; ++P) {
+        epilogue_cells(P, re, im, cell, kappa);
+        wave_sync();
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const int j4 = 4 * (le + 64 * q);
+          const float4 z01 = *reinterpret_cast<const float4*>(cell + j4);
+          const float4 z23 = *reinterpret_cast<const float4*>(cell + j4 + 2);
+          const float4 q01 = *reinterpret_cast<const float4*>(cell + kMirrorBase + j4);
+          const float4 q23 = *reinterpret_cast<const float4*>(cell + kMirrorBase + j4 + 2);
+          uint32_t wa = 0, wb = 0;
+#define SONO_BIN(B, ZR, ZI, PR, PI)                                          \
+  {                                                                          \
+    const float ar = (ZR) + (PR), ai = (ZI) - (PI);                          \
+    const float br = (ZI) + (PI), bi = (PR) - (ZR);                          \
+    wa = put_index<PLUGIN, B>(__builtin_fmaf(ar, ar, ai * ai), fs, wa);      \
+    wb = put_index<PLUGIN, B>(__builtin_fmaf(br, br, bi * bi), fs, wb);      \
+  }
+          SONO_BIN(0, z01.x, z01.y, q01.x, q01.y)
+          SONO_BIN(1, z01.z, z01.w, q01.z, q01.w)
+          SONO_BIN(2, z23.x, z23.y, q23.x, q23.y)
+          SONO_BIN(3, z23.z, z23.w, q23.z, q23.w)
+#undef SONO_BIN
+          const int kq = 128 * P + le + 64 * q;
+          if (4 * kq >= (int)p.bin_lo && 4 * kq < (int)p.bin_hi)
+            reinterpret_cast<uint2*>(slot)[rgba_flush::slot_cell(kq, fg) * 2 + (wave & 1)] = make_uint2(shifted ? wb : wa, wb);
+        }
+        wave_sync();  // the buffer is rewritten by the next half / the next iteration's transpose
+      }
+    }
+    fetch(first_frame(it + 1));
+    if (i == 7) __syncthreads();  // this round's slot is complete and everyone is done reading the other one
+    const uint64_t nround = (it + 1) >> 3;
+    if (nround > 0 && nround <= rounds) {
+      const int ni = (int)((it + 1) & 7);
+      rgba_flush::flush_quarter_load(fq, slots + ((nround - 1) & 1) * (kSlotBytes / 4), ni & 3, wave + 16 * (ni >> 2), lane);
+    }
+  }
+}
+
 }  // namespace fast2048
 
 // W_2048^(l*k1) as [k1][l] float2 (cos, -sin), k1 < 32, l < 64, computed in double.
@@ -357,10 +496,20 @@ bool fast2048_available(const StftParams& p) {
   return !(p.out_bins & 3) && !(p.out_bin0 & 3) && !(reinterpret_cast<uintptr_t>(p.out) & 3);
 }
 
+// The image output needs whole 16-bin groups, the flipped full-height row mapping, a colour table and the scratch
+// buffer (fast_rgba_scratch_bytes()).
+bool fast2048_rgba_available(const StftParams& p) {
+  if (p.n != 2048 || p.fast_mode != 1 || !p.fast_table || p.nframes < 2) return false;
+  if ((p.bin_lo & 15) || (p.bin_hi & 15) || p.bin_lo >= p.bin_hi) return false;
+  if (p.row_of_bin0 != (int32_t)p.bin_hi - 1) return false;
+  return p.width != 0 && p.width <= ((uint64_t)1 << 24) && p.lut;
+}
+
 // Returns 1 if this launch is not served here.
 int launch_stft_fast2048(const StftParams& p, void* stream_v) {
   using namespace fast2048;
-  if (!fast2048_available(p)) return 1;
+  const bool rgba = p.out_kind == SONO_OUT_RGBA8;
+  if (rgba ? !(fast2048_rgba_available(p) && p.tile_scratch) : !fast2048_available(p)) return 1;
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_v);
   FastScale fs = make_fast_scale(p.scale_mode, p.n, p.gain_db, p.range_db);
   fs.b -= 2.0f * fs.a;  // the pair separation leaves 2*X: |2X|^2 = 4|X|^2
@@ -373,6 +522,28 @@ int launch_stft_fast2048(const StftParams& p, void* stream_v) {
   const uint32_t grid = (uint32_t)(need < (uint64_t)cus ? need : (uint64_t)cus);  // persistent: one workgroup per CU
   const float2* table = reinterpret_cast<const float2*>(p.fast_table);
   const bool plugin = p.scale_mode == SONO_SCALE_PLUGIN_DB, i16 = p.in_kind == SONO_IN_I16, feat = p.out_kind == SONO_OUT_FEATURES;
+  if (rgba) {
+    const uint64_t nr = (p.nframes + rgba_flush::kRoundFrames - 1) / rgba_flush::kRoundFrames;
+    const uint32_t rgrid = (uint32_t)(nr < (uint64_t)cus ? nr : (uint64_t)cus);
+    uint8_t* tiles = reinterpret_cast<uint8_t*>(p.tile_scratch);
+#define SONO_R2048(PL, In, H)                                                                                   \
+  do {                                                                                                          \
+    auto kern = stft2048_rgba_kernel<PL, In, H>;                                                                \
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,    \
+                            kLdsBytes) != hipSuccess)                                                           \
+      return SONO_ERR_DEVICE;                                                                                   \
+    hipLaunchKernelGGL(kern, dim3(rgrid), dim3(kWaves * 64), kLdsBytes, stream, p, fs, table, tiles);           \
+  } while (0)
+#define SONO_R2048_H(PL, In)                                                \
+  do {                                                                      \
+    if (p.hop == 512) SONO_R2048(PL, In, 8); else SONO_R2048(PL, In, 0);    \
+  } while (0)
+    if (plugin) { if (i16) SONO_R2048_H(true, int16_t); else SONO_R2048_H(true, float); }
+    else { if (i16) SONO_R2048_H(false, int16_t); else SONO_R2048_H(false, float); }
+#undef SONO_R2048_H
+#undef SONO_R2048
+    return hipGetLastError() == hipSuccess ? SONO_OK : SONO_ERR_DEVICE;
+  }
 #define SONO_L2048(PL, In, FE, H)                                                                               \
   do {                                                                                                          \
     auto kern = stft2048_kernel<PL, In, FE, H>;                                                                 \

@@ -57,6 +57,7 @@ void build_fast_table_1024(std::vector<float>& t);
 // kernels_fast512.hip: float32 kernel for 512-point frames with exact roots of unity (fast_mode 1, fast_table from
 // build_fast_table_512); colour indices and per-frame peaks.  Returns 1 if it does not serve this launch.
 int launch_stft_fast512(const StftParams& p, void* hip_stream);
+bool fast2048_rgba_available(const StftParams& p);
 bool fast512_rgba_available(const StftParams& p);  // the kernel can write the RGBA image itself (given tile_scratch)
 void build_fast_table_512(std::vector<float>& t);
 // kernels_fast2048.hip: the same for 2048-point frames (one complex transform per wavefront), exact roots only.

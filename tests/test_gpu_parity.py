@@ -780,17 +780,17 @@ def _image_of_indices(idx, width, lut):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("hop", [128, 96])
-def test_fast_512_image_writer_rounds_tails_and_bands(hop):
-    """The 512-point kernel writes the RGBA image itself (rounds of 256 frames per workgroup, written out during
-    the next round): frame counts around the block size (4), the round size (256) and several rounds, with and
-    without the wrapped last frame, a band of 16-bin groups, int16 samples, and the plugin flavour with its own
-    twiddle table; every image must be the colour map applied to the indices the uint8 output of the same
-    arithmetic gives (bit-identical), which the other tests hold to the checker."""
-    n = 512
+@pytest.mark.parametrize("n,hop", [(512, 128), (512, 96), (2048, 512), (2048, 200)])
+def test_fast_512_2048_image_writer_rounds_tails_and_bands(n, hop):
+    """The 512- and 2048-point kernels write the RGBA image themselves (rounds of 256 frames per workgroup, written
+    out during the next round): frame counts around the block size (4 / 2), the round size (256) and several
+    rounds, with and without the wrapped last frame, a band of 16-bin groups, int16 samples, and (512) the plugin
+    flavour with its own twiddle table; every image must be the colour map applied to the indices the uint8 output
+    of the same arithmetic gives (bit-identical), which the other tests hold to the checker."""
+    H = n // 2
     rng = np.random.default_rng(17)
     lut = (np.arange(1024, dtype=np.uint32) * 11 % 253).astype(np.uint8)
-    for frames in list(range(8, 21)) + [131, 255, 256, 257, 258, 259, 513, 1100, 256 * 300 + 2]:
+    for frames in list(range(8, 21)) + [131, 255, 256, 257, 258, 259, 513, 1100, 256 * (300 if n == 512 else 260) + 3]:
         for extra in (0, 37):                                   # 0: (L-N) % hop == 0, one frame more than columns
             L = n + hop * (frames - 1) + extra
             x = (rng.standard_normal(L) * 0.1).astype(np.float32)
@@ -801,20 +801,20 @@ def test_fast_512_image_writer_rounds_tails_and_bands(hop):
                 idx, img = e8.stft(x), er.stft(x)
                 g = er.geometry(L)
             assert idx.shape[0] == g.frames and g.frames - g.width == (1 if extra == 0 else 0)
-            assert img.shape == (256, g.width, 4)
+            assert img.shape == (H, g.width, 4)
             assert np.array_equal(img, _image_of_indices(idx, g.width, lut)), (frames, extra)
             if frames in (8, 13, 259, 1100):
                 with worker_engine(n, hop, F.ARITH_FAST_F32, bin_lo=32, bin_hi=208) as eb:
                     eb.set_colormap(lut)
                     band = eb.stft(x)
-                assert np.array_equal(band, img[256 - 208:256 - 32]), (frames, extra)    # the band is a crop of the image
+                assert np.array_equal(band, img[H - 208:H - 32]), (frames, extra)    # the band is a crop of the image
                 q = np.round(x * 32767).astype(np.int16)
                 with worker_engine(n, hop, F.ARITH_FAST_F32, out_kind=F.OUT_U8_INDEX, in_kind=F.IN_I16) as e8, \
                         worker_engine(n, hop, F.ARITH_FAST_F32, in_kind=F.IN_I16) as er:
                     er.set_colormap(lut)
                     assert np.array_equal(er.stft(q), _image_of_indices(e8.stft(q), g.width, lut))
     # plugin flavour (recurrence twiddle table, gain/range quantiser): image == colour map of its own indices
-    for frames in (9, 300, 777):
+    for frames in (9, 300, 777) if n == 512 else ():
         L = n + hop * (frames - 1) + 5
         x = (rng.standard_normal(L) * 0.1).astype(np.float32)
         with plugin_engine(n, hop, F.ARITH_FAST_F32, out_kind=F.OUT_U8_INDEX) as e8, \
