@@ -229,6 +229,7 @@ def main():
             "rgba_worker_512_hop128": dict(out="rgba", fft_n=512, hop=128),      # the page's default FFT size (main.js:886-889)
             "features_plugin_512_hop128": dict(out="features", path="plugin", fft_n=512, hop=128),
             "u8_worker_2048_hop512": dict(out="u8", fft_n=2048, hop=512),
+            "rgba_worker_2048_hop512": dict(out="rgba", fft_n=2048, hop=512),
             "u8_plugin_2048_hop512": dict(out="u8", path="plugin", fft_n=2048, hop=512),
             "rgba_plugin_4096_hop256_bins160-1280_60s": dict(out="rgba", path="plugin", fft_n=4096, hop=256, bin_lo=160,
                                                             bin_hi=1280, samples=c4),
