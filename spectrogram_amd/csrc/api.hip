@@ -310,7 +310,6 @@ static uint32_t fast_mode_of(const sono_ctx* c) {
   const uint32_t fn = c->cfg.fft_n;
   if (c->cfg.arith != SONO_ARITH_FAST_F32 || (fn != 1024 && fn != 512 && fn != 2048) || c->d_fb_bin) return 0;
   if (c->cfg.twiddle_mode == SONO_TW_ACCURATE && !c->host_twiddles) return c->d_fast ? 1 : 0;
-  if (fn == 2048) return 0;  // table twiddles: the 512- and 1024-point kernels only
   // table twiddles: the kernel folds the first butterfly of every stage, so that factor must be 1
   for (uint32_t T = 1; T < c->cfg.fft_n; T <<= 1)
     if (c->h_cos[T - 1] != 1.0 || c->h_sin[T - 1] != 0.0) return 0;

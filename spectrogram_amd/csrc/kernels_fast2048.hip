@@ -96,6 +96,41 @@ __device__ __forceinline__ void fft32(float (&re)[32], float (&im)[32]) {
   }
 }
 
+__host__ __device__ constexpr int brev6(int v) { return (brev5(v & 31) << 1) | (v >> 5); }
+
+// The same 32-point network with twiddles from a table (the plugin's recurrence factors or a host table: not exact
+// roots of unity, so every butterfly must use the very factor the reference uses, spectrogram.esm.js:176-190).
+// Registers in position order.  tw(half, j): factor (cos, sin) of the butterfly at position j of the stage with half
+// size `half`.  FIRST: the first five stages of the transform, where j == 0 is the factor (1, 0) exactly in every table
+// this kernel accepts (checked on the host).
+template <bool FIRST, class TwFn>
+__device__ __forceinline__ void fft32_table(float (&re)[32], float (&im)[32], TwFn tw) {
+#pragma unroll
+  for (int s = 0; s < 5; ++s) {
+    const int half = 1 << s;
+#pragma unroll
+    for (int j = 0; j < half; ++j) {
+      float2 w = make_float2(1.0f, 0.0f);
+      if (!FIRST || j != 0) w = tw(half, j);
+#pragma unroll
+      for (int g = 0; g < 32; g += 2 * half) {
+        const int i0 = g + j, i1 = i0 + half;
+        const float ar = re[i0], ai = im[i0], br = re[i1], bi = im[i1];
+        if (FIRST && j == 0) {
+          re[i0] = ar + br; im[i0] = ai + bi;
+          re[i1] = ar - br; im[i1] = ai - bi;
+        } else {  // o1 = a + w*b, o2 = a - w*b = 2a - o1
+          const float o1r = __builtin_fmaf(-w.y, bi, __builtin_fmaf(w.x, br, ar));
+          const float o1i = __builtin_fmaf(w.y, br, __builtin_fmaf(w.x, bi, ai));
+          re[i0] = o1r; im[i0] = o1i;
+          re[i1] = __builtin_fmaf(2.0f, ar, -o1r);
+          im[i1] = __builtin_fmaf(2.0f, ai, -o1i);
+        }
+      }
+    }
+  }
+}
+
 __device__ __forceinline__ void wave_sync() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
@@ -130,22 +165,38 @@ __device__ __forceinline__ uint32_t put_index(float msq, const FastScale& fs, ui
   }
 }
 
-// The complex 2048-point transform of one wavefront: in, lane l register brev5(a) = z[64a + l]; out, register k2 =
-// Z[k1 + 32*(2*k2 + par)] with k1 = lane & 31 and par = 1 in lanes 0..31 (differences), 0 in lanes 32..63.
-__device__ __forceinline__ void transform2048(float (&re)[32], float (&im)[32], const float2* tw_lds, float* plane, int lane) {
-  fft32(re, im);  // Y_l[k1]
-#pragma unroll
-  for (int k1 = 1; k1 < 32; ++k1) {
-    const float2 t = tw_lds[k1 * 64 + lane];
-    const float ur = __builtin_fmaf(re[k1], t.x, -im[k1] * t.y);
-    const float ui = __builtin_fmaf(re[k1], t.y, im[k1] * t.x);
-    re[k1] = ur;
-    im[k1] = ui;
-  }
-  // transpose: lane l, register k1 -> lane k1 + 32*hb, register m = y[m + 32*hb] of row k1 (natural order in m)
+// The complex 2048-point transform of one wavefront: in, lane l register brev5(a) = z[64a + l].
+// Exact roots (TABLE false): out, register k2 = Z[k1 + 32*(2*k2 + par)] with k1 = lane & 31 and par = 1 in lanes 0..31
+// (differences), 0 in lanes 32..63.
+// TABLE: the reference's radix-2 network itself, factor by factor.  Lane l's registers are the positions
+// 32*brev6(l) + r of the bit-reversed order, so the first pass is the stages T = 1..16 with wave-uniform factors
+// (tw_flat, the context's table: stage with half size T at [T-1, 2T-1)); the transpose hands lane k1 + 32*hb the
+// positions 32*(32*hb + m) + k1, m = 0..31; stages T = 32t, t = 1..16, pair registers m, m + t with factor
+// 32*(m mod t) + k1 (rows t-1+j of tw_lds, [63][32]); the last stage T = 1024 pairs the two lanes of a row with factor
+// 32*m + k1 (rows 31 + m): registers m and m + 16 trade halves, each lane does 16 butterflies, and they trade back.
+// Out: register m = Z[k1 + 32*m + 1024*hb].
+template <bool TABLE>
+__device__ __forceinline__ void transform2048(float (&re)[32], float (&im)[32], const float2* tw_lds, const float2* tw_flat,
+                                              float* plane, int lane) {
   const int k1r = lane & 31, hb = lane >> 5;
+  if constexpr (TABLE) {
+    fft32_table<true>(re, im, [&](int half, int j) { return tw_flat[half - 1 + j]; });
+  } else {
+    fft32(re, im);  // Y_l[k1]
 #pragma unroll
-  for (int k1 = 0; k1 < 32; ++k1) plane[k1 * kPlaneStride + lane] = re[k1];
+    for (int k1 = 1; k1 < 32; ++k1) {
+      const float2 t = tw_lds[k1 * 64 + lane];
+      const float ur = __builtin_fmaf(re[k1], t.x, -im[k1] * t.y);
+      const float ui = __builtin_fmaf(re[k1], t.y, im[k1] * t.x);
+      re[k1] = ur;
+      im[k1] = ui;
+    }
+  }
+  // transpose: lane l, register k1 -> lane k1 + 32*hb, register m = y[m + 32*hb] of row k1 (natural order in m);
+  // TABLE: lane l's column is its position block brev6(l)
+  const int col = TABLE ? brev6(lane) : lane;
+#pragma unroll
+  for (int k1 = 0; k1 < 32; ++k1) plane[k1 * kPlaneStride + col] = re[k1];
   wave_sync();
   {
     const float4* row = reinterpret_cast<const float4*>(plane + k1r * kPlaneStride + 32 * hb);
@@ -157,7 +208,7 @@ __device__ __forceinline__ void transform2048(float (&re)[32], float (&im)[32], 
   }
   wave_sync();
 #pragma unroll
-  for (int k1 = 0; k1 < 32; ++k1) plane[k1 * kPlaneStride + lane] = im[k1];
+  for (int k1 = 0; k1 < 32; ++k1) plane[k1 * kPlaneStride + col] = im[k1];
   wave_sync();
   {
     const float4* row = reinterpret_cast<const float4*>(plane + k1r * kPlaneStride + 32 * hb);
@@ -168,6 +219,27 @@ __device__ __forceinline__ void transform2048(float (&re)[32], float (&im)[32], 
     }
   }
   wave_sync();
+  if constexpr (TABLE) {
+    fft32_table<false>(re, im, [&](int half, int j) { return tw_lds[(half - 1 + j) * 32 + k1r]; });  // stages T = 32..512
+    const float2* wrow = tw_lds + (31 + 16 * hb) * 32 + k1r;
+#pragma unroll
+    for (int m = 0; m < 16; ++m) {
+      swap32(re[m], re[m + 16]);
+      swap32(im[m], im[m + 16]);
+      // both lanes: a = position mu (register m), b = position mu + 32 (register m + 16), mu = m + 16*hb
+      const float2 w = wrow[m * 32];
+      const float ar = re[m], ai = im[m], br = re[m + 16], bi = im[m + 16];
+      const float o1r = __builtin_fmaf(-w.y, bi, __builtin_fmaf(w.x, br, ar));
+      const float o1i = __builtin_fmaf(w.y, br, __builtin_fmaf(w.x, bi, ai));
+      re[m] = o1r; im[m] = o1i;
+      re[m + 16] = __builtin_fmaf(2.0f, ar, -o1r);
+      im[m + 16] = __builtin_fmaf(2.0f, ai, -o1i);
+      swap32(re[m], re[m + 16]);
+      swap32(im[m], im[m + 16]);
+      // lower lane: sums mu = m (own) and m + 16 (the upper lane's); upper lane: differences mu = m and m + 16
+    }
+    return;
+  }
   // Radix-2 stage across the lane pair (k1, k1 + 32).  Round 1: registers m and m + 16 trade halves, so the lower
   // lane holds y[m] (in re[m]) and y[m + 32] (in re[m + 16]) for m < 16 and the upper lane the same for
   // m' = m + 16; sums and differences are taken in place.  Round 2: the sum register m and the difference register
@@ -183,8 +255,6 @@ __device__ __forceinline__ void transform2048(float (&re)[32], float (&im)[32], 
     re[m + 16] = sr; im[m + 16] = si;
     swap32(re[m], re[m + 16]);
     swap32(im[m], im[m + 16]);
-    // lower lane: re[m] = d (own m), re[m+16] = d (the upper lane's m, i.e. index m + 16)
-    // upper lane: re[m] = s (the lower lane's m), re[m+16] = s (own m, i.e. index m + 16)
   }
   if (hb == 0) {  // the differences take the factor W_64^m before their 32-point transform
 #pragma unroll
@@ -203,7 +273,7 @@ __device__ __forceinline__ void transform2048(float (&re)[32], float (&im)[32], 
 #pragma unroll
     for (int m = 0; m < 32; ++m) { re[m] = tr[m]; im[m] = ti[m]; }
   }
-  fft32(re, im);  // register k2: Z[k1 + 32*(2*k2 + par)], par = 1 in the lower lanes (differences), 0 in the upper
+  fft32(re, im);
 }
 
 // Epilogue half P: Z[512P + j] to cell j and the partners Z[2048 - 512P - j] to cell kMirrorBase + j (j <= 512).  With
@@ -219,13 +289,44 @@ __device__ __forceinline__ void epilogue_cells(int P, const float (&re)[32], con
   if (kappa == 0) cell[kMirrorBase] = P ? make_float2(re[24], im[24]) : make_float2(re[0], im[0]);
 }
 
-template <bool PLUGIN, typename In, bool FEAT, int HOP64>
+// The same for the TABLE transform's register order (register m = Z[k1 + 32*m + 1024*hb]): the lower lane of a row holds
+// the bins (registers 16P..16P+15 -> cells 32r + k1), the upper lane the partners (register 16(1-P) + r is
+// Z[2048 - 512P - j] with j = 512 - 32r - k1); j = 0 is Z[0] (lower lane, k1 = 0, register 0) in half 0 and Z[1536]
+// (upper lane, k1 = 0, register 16) in half 1.
+__device__ __forceinline__ void epilogue_cells_table(int P, const float (&re)[32], const float (&im)[32], float2* cell, int le) {
+  const int k1 = le & 31;
+  const bool up = le >= 32;
+  float2* c0 = cell + (up ? kMirrorBase + 512 - k1 : k1);
+  const int step = up ? -32 : 32;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int lo = 16 * P + r, hi = 16 * (1 - P) + r;
+    float rl = re[lo], rh = re[hi], il = im[lo], ih = im[hi];
+    // (opaque copies: the selects below must stay selects of two registers, not become an indexed register read)
+    asm("" : "+v"(rl)); asm("" : "+v"(rh)); asm("" : "+v"(il)); asm("" : "+v"(ih));
+    c0[r * step] = make_float2(up ? rh : rl, up ? ih : il);
+  }
+  if (k1 == 0 && up == (P == 1)) cell[kMirrorBase] = make_float2(re[16 * P], im[16 * P]);
+}
+
+template <bool PLUGIN, typename In, bool FEAT, int HOP64, bool TABLE>
 __global__ __launch_bounds__(kWaves * 64) void stft2048_kernel(StftParams p, FastScale fs, const float2* __restrict__ tw_table) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float2* tw_lds = reinterpret_cast<float2*>(smem);
   float* win_lds = reinterpret_cast<float*>(smem + kTwBytes);
+  const float2* __restrict__ tw_flat = reinterpret_cast<const float2*>(p.twiddles);
   for (int i = threadIdx.x; i < 2048; i += kWaves * 64) {
-    tw_lds[i] = tw_table[i];
+    if constexpr (TABLE) {
+      const int r = i >> 5, k = i & 31;  // rows 0..30: stage T = 32t, factor 32j + k (r = t-1+j); rows 31..62: T = 1024, 32m + k
+      if (r < 31) {
+        const int t = 1 << (31 - __builtin_clz(r + 1)), j = r + 1 - t;
+        tw_lds[i] = tw_flat[32 * t - 1 + 32 * j + k];
+      } else if (r < 63) {
+        tw_lds[i] = tw_flat[1023 + 32 * (r - 31) + k];
+      }
+    } else {
+      tw_lds[i] = tw_table[i];
+    }
     win_lds[i] = p.window[i];
   }
   __syncthreads();
@@ -270,7 +371,7 @@ __global__ __launch_bounds__(kWaves * 64) void stft2048_kernel(StftParams p, Fas
         }
       }
     }
-    transform2048(re, im, tw_lds, plane, lane);
+    transform2048<TABLE>(re, im, tw_lds, tw_flat, plane, lane);
 
     // Epilogue in two halves of 512 bins.
     int le = lane;
@@ -282,7 +383,7 @@ __global__ __launch_bounds__(kWaves * 64) void stft2048_kernel(StftParams p, Fas
     const bool st_a = fb >= f0, st_b = true;  // fb + 1 < nframes always; frame fb belongs to this wavefront unless shifted
 #pragma unroll
     for (int P = 0; P < 2; ++P) {
-      epilogue_cells(P, re, im, cell, kappa);
+      if constexpr (TABLE) epilogue_cells_table(P, re, im, cell, le); else epilogue_cells(P, re, im, cell, kappa);
       wave_sync();
 #pragma unroll
       for (int q = 0; q < 2; ++q) {
@@ -426,7 +527,7 @@ __global__ __launch_bounds__(kWaves * 64) void stft2048_rgba_kernel(StftParams p
         re[brev5(a)] = raw[a] * w;
         im[brev5(a)] = raw[a + (HOP64 > 0 ? HOP64 : 32)] * w;
       }
-      transform2048(re, im, tw_lds, plane, lane);
+      transform2048<false>(re, im, tw_lds, nullptr, plane, lane);
 
       int le = lane;
       asm volatile("" : "+v"(le));  // (keeps loop-invariant epilogue addresses out of registers the transforms need)
@@ -489,7 +590,8 @@ void build_fast_table_2048(std::vector<float>& t) {
 }
 
 bool fast2048_available(const StftParams& p) {
-  if (p.n != 2048 || p.fast_mode != 1 || !p.fast_table || p.nframes < 2) return false;
+  if (p.n != 2048 || p.nframes < 2) return false;
+  if (!((p.fast_mode == 1 && p.fast_table) || (p.fast_mode == 2 && p.twiddles))) return false;
   if ((p.bin_lo & 3) || (p.bin_hi & 3) || p.bin_lo >= p.bin_hi) return false;
   if (p.out_kind == SONO_OUT_FEATURES) return true;
   if (p.out_kind != SONO_OUT_U8_INDEX) return false;
@@ -522,6 +624,7 @@ int launch_stft_fast2048(const StftParams& p, void* stream_v) {
   const uint32_t grid = (uint32_t)(need < (uint64_t)cus ? need : (uint64_t)cus);  // persistent: one workgroup per CU
   const float2* table = reinterpret_cast<const float2*>(p.fast_table);
   const bool plugin = p.scale_mode == SONO_SCALE_PLUGIN_DB, i16 = p.in_kind == SONO_IN_I16, feat = p.out_kind == SONO_OUT_FEATURES;
+  const bool tab = p.fast_mode == 2;
   if (rgba) {
     const uint64_t nr = (p.nframes + rgba_flush::kRoundFrames - 1) / rgba_flush::kRoundFrames;
     const uint32_t rgrid = (uint32_t)(nr < (uint64_t)cus ? nr : (uint64_t)cus);
@@ -546,7 +649,11 @@ int launch_stft_fast2048(const StftParams& p, void* stream_v) {
   }
 #define SONO_L2048(PL, In, FE, H)                                                                               \
   do {                                                                                                          \
-    auto kern = stft2048_kernel<PL, In, FE, H>;                                                                 \
+    if (tab) SONO_L2048_T(PL, In, FE, H, true); else SONO_L2048_T(PL, In, FE, H, false);                        \
+  } while (0)
+#define SONO_L2048_T(PL, In, FE, H, T)                                                                          \
+  do {                                                                                                          \
+    auto kern = stft2048_kernel<PL, In, FE, H, T>;                                                               \
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,    \
                             kLdsBytes) != hipSuccess)                                                           \
       return SONO_ERR_DEVICE;                                                                                   \
@@ -560,6 +667,7 @@ int launch_stft_fast2048(const StftParams& p, void* stream_v) {
   if (plugin) { if (i16) SONO_L2048_F(true, int16_t); else SONO_L2048_F(true, float); }
   else { if (i16) SONO_L2048_F(false, int16_t); else SONO_L2048_F(false, float); }
 #undef SONO_L2048_F
+#undef SONO_L2048_T
 #undef SONO_L2048
   return hipGetLastError() == hipSuccess ? SONO_OK : SONO_ERR_DEVICE;
 }

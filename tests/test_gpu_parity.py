@@ -822,3 +822,41 @@ def test_fast_512_2048_image_writer_rounds_tails_and_bands(n, hop):
             er.set_colormap(lut)
             idx, img = e8.stft(x), er.stft(x)
         assert np.array_equal(img, lut.reshape(256, 4)[idx.T[::-1]]), frames
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("hop", [512, 300])
+def test_fast_2048_plugin_table_kernel_against_oracle(hop):
+    """getFrequencies at 2048 points in float32 with the plugin's own recurrence twiddles (the one-transform-per-
+    wavefront kernel in its table flavour: every butterfly takes the factor the reference takes,
+    spectrogram.esm.js:176-190): a loud tone over weak noise, so that bins 60-80 dB below the peak -- where wrong
+    factors would show -- are inside the displayed range; every frame count from 8 to 20 (blocks shifted back at the
+    end), a band, int16 samples; colour indices within 1 LSB of the checker, and per-frame peaks consistent with
+    the indices."""
+    n = 2048
+    rng = np.random.default_rng(23)
+    for frames in list(range(8, 21)) + [77]:
+        L = n + hop * frames                                     # strict rule: a + N < L
+        x = (rng.standard_normal(L) * 2e-4).astype(np.float32)
+        x += (0.8 * np.sin(np.arange(L) * (0.41 + 0.003 * frames))).astype(np.float32)
+        ref = oracle.plugin_get_frequencies(x, n, n - hop)
+        assert ref.shape[0] == frames
+        with plugin_engine(n, hop, F.ARITH_FAST_F32) as eng:
+            got = eng.stft(x)
+        d = cyc_diff(got, ref)
+        assert got.shape == ref.shape and d.max() <= 1 and (d != 0).mean() < 0.02, (frames, d.max())
+        if frames in (8, 13, 20, 77):
+            with plugin_engine(n, hop, F.ARITH_FAST_F32, bin_lo=20, bin_hi=600) as eng:
+                assert np.array_equal(eng.stft(x), got[:, 20:600])
+            q = np.round(x * 32767).astype(np.int16)
+            xf = (q.astype(np.float32) / 32768).astype(np.float32)
+            ref16 = oracle.plugin_get_frequencies(xf, n, n - hop)
+            with plugin_engine(n, hop, F.ARITH_FAST_F32, in_kind=F.IN_I16) as eng:
+                d16 = cyc_diff(eng.stft(q), ref16)
+            assert d16.max() <= 1
+            with plugin_engine(n, hop, F.ARITH_FAST_F32, out_kind=F.OUT_FEATURES, bin_lo=4, bin_hi=n // 2 - 4) as eng:
+                ft = eng.stft(x)
+            assert len(ft) == frames
+            rows = np.arange(frames)
+            assert np.array_equal(ft["peak_idx"], got[rows, ft["peak_bin"]])           # same arithmetic, same index
+            assert (got[:, 4:n // 2 - 4].max(axis=1) == ft["peak_idx"]).all()          # and it is the frame's largest
