@@ -77,10 +77,19 @@ __device__ __forceinline__ uint32_t fast_index(float mag_sq, const FastScale& s)
     t = fminf(fmaxf(t, 0.0f), 255.0f);  // NaN -> 0 like the reference's failed comparison
     return (uint32_t)t;
   }
-  const float t = fmaxf(lg * s.a + s.b, s.t_floor);  // NaN takes the floor, as `n > 1e-12` fails for NaN
-  if (!(t >= 1.0f)) return 0;    // r < -gain-range
-  if (t > 256.0f) return 255;    // r > -gain
-  return ((uint32_t)t) & 255u;   // t == 256 wraps to 0 like the Uint8Array store
+  // NaN takes the floor, as `n > 1e-12` fails for NaN.  The conversion saturates: t < 1 (r < -gain-range) gives 0,
+  // t >= 256 (r > -gain) gives 255.  (The reference stores 256 -> 0 when r == -gain exactly, spectrogram.esm.js:534;
+  // in float32 a t of exactly 256 says no more than "r is within rounding of -gain", where the reference gives 255 on
+  // both sides, so 255 it is.  The bit-identical arithmetic keeps the wrap.)
+  const float t = __builtin_floorf(fmaxf(__builtin_fmaf(lg, s.a, s.b), s.t_floor));
+  return __builtin_amdgcn_cvt_pk_u8_f32(t, 0, 0u);
+}
+
+// The plugin quantiser of fast_index, packed into byte BYTE of `acc`.
+template <int BYTE>
+__device__ __forceinline__ uint32_t fast_plugin_byte(float mag_sq, const FastScale& s, uint32_t acc) {
+  const float t = __builtin_floorf(fmaxf(__builtin_fmaf(__log2f(mag_sq), s.a, s.b), s.t_floor));
+  return __builtin_amdgcn_cvt_pk_u8_f32(t, BYTE, acc);
 }
 
 __device__ __forceinline__ float fast_db(float mag_sq, const FastScale& s) {
