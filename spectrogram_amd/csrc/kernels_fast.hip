@@ -43,16 +43,18 @@ static_assert(kMirrorOffset + 257 * 8 <= kFftBufBytes, "epilogue half must fit t
 constexpr int kTwBytes = 32 * 32 * 8;
 constexpr int kWinBytes = 32 * kPlaneStride * 4;   // window as [l][kPlaneStride]: lane l reads w[32a + l], a = 0..31, as 8 x 16 B
 constexpr int lds_bytes(int waves) { return kTwBytes + kWinBytes + waves * 2 * kFftBufBytes; }  // 16 waves: 160256
-// RGBA output: a workgroup round covers 256 consecutive frames (16 per wavefront, four iterations =
-// 64 frame groups of 4); their colour indices are parked in one of the workgroup's two slots of a
-// global scratch buffer as [reader wavefront 16][frame group 64][bin quad 8] x 16 bytes (four frames x
-// four bins), 128 KiB, which stays in L2 / Infinity Cache.
-constexpr int kTileFrames = 16;                    // frames per wavefront and round
-using rgba_flush::kRoundFrames;
+// RGBA output: a workgroup round covers 128 consecutive frames (8 per wavefront, two iterations =
+// 32 frame groups of 4); their colour indices are parked in one of the workgroup's two slots of a
+// global scratch buffer as [reader wavefront 16][frame group 32][bin quad 8] x 16 bytes (four frames x
+// four bins), 64 KiB, which is meant to stay in L2 / Infinity Cache.  (SONO_RF = 256: rounds of 256 frames, 1-KiB row
+// runs instead of 512-byte ones; measured 2 % slower: a slot line lives twice as long between its write and its read.)
+#ifndef SONO_RF
+#define SONO_RF 128
+#endif
+constexpr int kRoundFrames = SONO_RF;
+constexpr int kTileFrames = kRoundFrames / 16;     // frames per wavefront and round
 using rgba_flush::kRoundBytes;
 using rgba_flush::kLutBytes;
-using rgba_flush::flush_quarter_load;
-using rgba_flush::flush_quarter_store;
 static_assert(kRoundFrames == kMaxWaves * kTileFrames, "a round is one tile per wavefront");
 
 // cos/sin(2*pi*j/32), j = 0..15
@@ -173,9 +175,9 @@ __device__ __forceinline__ uint32_t put_index(float msq, const FastScale& fs, ui
 // instead of [frame][bin] indices.  A frame is one image COLUMN, so writing frames as they are
 // finished would scatter 16-byte pieces over 512 rows; partial 64-byte sectors cost the memory a
 // read-modify-write, and a store instruction that touches many cache lines is slow in the CU.  So the
-// workgroup parks the indices of a round (256 consecutive frames) in a scratch slot that stays in
+// workgroup parks the indices of a round (kRoundFrames consecutive frames) in a scratch slot that stays in
 // cache, meets at ONE barrier per round, and during the next round every wavefront writes its 32
-// image rows of the finished round, a quarter per iteration (flush_quarter), from the other slot.
+// image rows of the finished round, two quarters (of eight rows) per iteration (flush_quarter), from the other slot.
 // The stores of a quarter are issued after the next iteration's sample loads, so neither waits for
 // the other.  The two half-wavefronts first swap registers (v_permlane32_swap) so that a lane holds
 // the same four bins of all four frames of the iteration: one 16-byte scratch store per lane and
@@ -291,7 +293,8 @@ __global__ __launch_bounds__(kMaxWaves * 64, 4) void stft1024_u8_kernel(StftPara
   };
   Unit cur = locate(0);
   fetch(cur);
-  uint4 fq[2] = {};  // RGBA: this lane's slot reads for the quarter that the iteration writes out
+  constexpr int kPPI = RGBA ? 4 / kTileIters : 1;  // quarters written out per iteration
+  uint4 fq[kPPI][2] = {};  // RGBA: this lane's slot reads for the quarters that the iteration writes out
   // RGBA: one more round than there are frames for, which only writes out the last slot
   for (uint64_t it = 0; !RGBA || it < (rounds + 1) * kTileIters; ++it) {
     if (!RGBA && !cur.active) break;
@@ -305,7 +308,11 @@ __global__ __launch_bounds__(kMaxWaves * 64, 4) void stft1024_u8_kernel(StftPara
         const uint64_t round = it / kTileIters;
         if (round > 0) {
           const uint64_t frame0 = ((round - 1) * gridDim.x + vb) * kRoundFrames;
-          if (frame0 < p.nframes) flush_quarter_store(p, fq, lut_lds, frame0, (int)(it % kTileIters), wave, lane);
+          if (frame0 < p.nframes) {
+#pragma unroll
+            for (int j = 0; j < kPPI; ++j)
+              rgba_flush::flush_quarter_store<kRoundFrames>(p, fq[j], lut_lds, frame0, (int)(it % kTileIters) * kPPI + j, wave, lane);
+          }
         }
       }
     };
@@ -457,9 +464,9 @@ __global__ __launch_bounds__(kMaxWaves * 64, 4) void stft1024_u8_kernel(StftPara
         const auto sa = __builtin_amdgcn_permlane32_swap(wa2[0], wa2[1], false, false);
         const auto sb = __builtin_amdgcn_permlane32_swap(wb2[0], wb2[1], false, false);
         const int kq = 64 * P + l + 32 * h;               // reader wavefront kq >> 3, its quad kq & 7
-        const int fg = 4 * wave + (int)(it % kTileIters);  // frame group of the round
+        const int fg = kTileIters * wave + (int)(it % kTileIters);  // frame group of the round
         if (4 * kq >= (int)p.bin_lo && 4 * kq < (int)p.bin_hi)
-          reinterpret_cast<uint4*>(slot)[((kq >> 3) * 64 + fg) * 8 + (kq & 7)] = make_uint4(sa[0], sb[0], sa[1], sb[1]);
+          reinterpret_cast<uint4*>(slot)[rgba_flush::slot_cell<kRoundFrames>(kq, fg)] = make_uint4(sa[0], sb[0], sa[1], sb[1]);
       }
       wave_sync();  // the buffer is rewritten by the next half / the next iteration's transpose
     }
@@ -496,8 +503,12 @@ __global__ __launch_bounds__(kMaxWaves * 64, 4) void stft1024_u8_kernel(StftPara
       // wavefront is done reading the other slot, which the next round overwrites.
       if (it % kTileIters == kTileIters - 1) __syncthreads();
       const uint64_t nround = (it + 1) / kTileIters;
-      if (nround > 0 && nround <= rounds)
-        flush_quarter_load(fq, slots + ((nround - 1) & 1) * (kRoundBytes / 4), (int)((it + 1) % kTileIters), wave, lane);
+      if (nround > 0 && nround <= rounds) {
+#pragma unroll
+        for (int j = 0; j < kPPI; ++j)
+          rgba_flush::flush_quarter_load<kRoundFrames>(fq[j], slots + ((nround - 1) & 1) * (kRoundBytes / 4),
+                                                       (int)((it + 1) % kTileIters) * kPPI + j, wave, lane);
+      }
     }
   }
 }

@@ -1,6 +1,6 @@
-// The image side of the kernels that write RGBA themselves: a workgroup parks the colour indices of a round of 256
-// consecutive frames in a slot of a global scratch buffer that stays in cache, and writes the finished round out
-// as 1-KiB pixel runs per image row while it transforms the next one.
+// The image side of the kernels that write RGBA themselves: a workgroup parks the colour indices of a round of RF
+// (256 or 128) consecutive frames in a slot of a global scratch buffer that stays in cache, and writes the finished
+// round out as pixel runs of 4*RF bytes per image row while it transforms the next one.
 #ifndef SONO_RGBA_FLUSH_H
 #define SONO_RGBA_FLUSH_H
 
@@ -12,7 +12,7 @@
 namespace sono {
 namespace rgba_flush {
 
-constexpr int kRoundFrames = 256;                  // frames per workgroup round
+constexpr int kRoundFrames = 256;                  // frames per workgroup round (largest)
 // slot: [reader wavefront 16][frame group 64][bin quad 8] x 16 bytes (four frames x four bins), 128 KiB; a
 // workgroup owns two of them
 constexpr int kRoundBytes = 128 * kRoundFrames * 4;
@@ -20,25 +20,28 @@ constexpr int kLutBytes = 1024;
 typedef uint32_t u32x4_unaligned __attribute__((ext_vector_type(4), aligned(4)));
 
 // cell of the bin quad kq (bins 4kq .. 4kq+3) of frame group fg (frames 4fg .. 4fg+3 of the round), in uint4 units
-__device__ __forceinline__ int slot_cell(int kq, int fg) { return ((kq >> 3) * 64 + fg) * 8 + (kq & 7); }
+template <int RF = 256>
+__device__ __forceinline__ int slot_cell(int kq, int fg) { return ((kq >> 3) * (RF / 4) + fg) * 8 + (kq & 7); }
 
-// Writes one quarter (`part` = 0..3) of a workgroup round (256 frames starting at frame `frame0`,
+// Writes one quarter (`part` = 0..3) of a workgroup round (RF frames starting at frame `frame0`,
 // indices in `slot`) to the RGBA image.  Wavefront w owns the 32 bins 32w .. 32w+31 (32 image rows) and
 // writes the eight rows of bins 32w + 8*part .. +7 per quarter, complete: per step u lane j reads the
 // bin quad 2*part + (j & 1) of the frame group 32u + (j >> 1), i.e. 4 bins x 4 frames, and stores four
-// 16-byte pixel runs; 32 lanes form a 512-byte run of one row and the two steps complete its 1-KiB run,
+// 16-byte pixel runs; 32 lanes form a 512-byte run of one row and the RF/128 steps complete its run of 4*RF bytes,
 // so that sectors are whole when they leave L2 (up to the ends of the run, which the neighbouring
 // workgroup completes).  Addresses are a wave-uniform base plus a 32-bit lane offset.
 // first half of it: the two slot reads of lane `lane` for quarter `part`
+template <int RF = 256>
 __device__ __forceinline__ void flush_quarter_load(uint4 (&q)[2], const uint32_t* __restrict__ slot, int part, int wave, int lane) {
   asm volatile("" : "+s"(wave));
   asm volatile("" : "+v"(lane));
   const int qsel = lane & 1, fsel = lane >> 1;
-  const uint4* sp = reinterpret_cast<const uint4*>(slot) + wave * (64 * 8) + fsel * 8 + 2 * part + qsel;
+  const uint4* sp = reinterpret_cast<const uint4*>(slot) + wave * ((RF / 4) * 8) + fsel * 8 + 2 * part + qsel;
 #pragma unroll
-  for (int u = 0; u < 2; ++u) q[u] = sp[u * 32 * 8];
+  for (int u = 0; u < RF / 128; ++u) q[u] = sp[u * 32 * 8];
 }
 // second half: colours and stores
+template <int RF = 256>
 __device__ __forceinline__ void flush_quarter_store(const StftParams& p, const uint4 (&q)[2], const uint32_t* lut_lds,
                                                     uint64_t frame0, int part, int wave, int lane) {
   // Everything here is invariant in the caller's frame loop; computing it in place is cheap, while
@@ -48,11 +51,11 @@ __device__ __forceinline__ void flush_quarter_store(const StftParams& p, const u
   const int qsel = lane & 1, fsel = lane >> 1;
   const int64_t width4 = (int64_t)p.width * 4;
   const uint32_t voff = (uint32_t)(4 - 4 * qsel) * (uint32_t)width4 + 16u * fsel;
-  const bool whole = frame0 + kRoundFrames <= p.nframes;  // workgroup-uniform
+  const bool whole = frame0 + RF <= p.nframes;  // workgroup-uniform
   const int bin0 = 32 * wave + 8 * part;                  // wave-uniform; the band is made of 16-bin groups
   if (bin0 < (int)p.bin_lo || bin0 >= (int)p.bin_hi) return;
 #pragma unroll
-  for (int u = 0; u < 2; ++u) {
+  for (int u = 0; u < RF / 128; ++u) {
     const uint64_t fl = frame0 + 128 * u + 4 * fsel;  // this lane's first frame
     const int nvalid = fl >= p.nframes ? 0 : (p.nframes - fl >= 4 ? 4 : (int)(p.nframes - fl));
     // row of bin (bin0 + 4 + i), column of frame group 32u
