@@ -449,18 +449,23 @@ __global__ __launch_bounds__(kWaves * 64) void stft2048_kernel(StftParams p, Fas
 }
 
 // RGBA: the image [row = row_of_bin0 - bin][column = col0 + frame] of LUT colours, with the slot mechanism of the
-// 1024-point kernel (sono_rgba_flush.h).  A workgroup round is 256 consecutive frames = eight iterations of 32 frames
-// (wavefront w: frames 32i + 2w, +1 of the round); a slot holds 1024 bins x 256 frames = 256 KiB as 32 reader units of
-// 32 bins; two wavefronts fill one 16-byte cell (four bins x four frames) with 8 bytes each.  During the next round
-// wavefront w writes out, in iteration i, quarter i & 3 of reader unit w + 16*(i >> 2).  The samples of an iteration
+// 1024-point kernel (sono_rgba_flush.h).  A workgroup round is kRF = 128 consecutive frames = four iterations of 32
+// frames (wavefront w: frames 32i + 2w, +1 of the round); a slot holds 1024 bins x 128 frames = 128 KiB as 32 reader
+// units of 32 bins; two wavefronts fill one 16-byte cell (four bins x four frames) with 8 bytes each.  During the next
+// round wavefront w writes out, in iteration i, quarter i of the reader units w and w + 16.  The samples of an iteration
 // and the slot reads of its quarter are issued at the end of the iteration before.  The colour table is read from
 // global memory: the transforms use all of the CU's LDS.
-constexpr int kSlotBytes = 2 * rgba_flush::kRoundBytes;
+#ifndef SONO_RF2048
+#define SONO_RF2048 128
+#endif
+constexpr int kRF = SONO_RF2048;
+constexpr int kRIters = kRF / 32;       // iterations per round
+constexpr int kFPI = 8 / kRIters;       // quarters a wavefront writes out per iteration (32 units x 4 quarters per round)
+constexpr int kSlotBytes = 1024 * kRF;
 
 template <bool PLUGIN, typename In, int HOP64>
 __global__ __launch_bounds__(kWaves * 64) void stft2048_rgba_kernel(StftParams p, FastScale fs, const float2* __restrict__ tw_table,
                                                                     uint8_t* __restrict__ tiles) {
-  using rgba_flush::kRoundFrames;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float2* tw_lds = reinterpret_cast<float2*>(smem);
   float* win_lds = reinterpret_cast<float*>(smem + kTwBytes);
@@ -480,13 +485,13 @@ __global__ __launch_bounds__(kWaves * 64) void stft2048_rgba_kernel(StftParams p
   const uint32_t vb = (gridDim.x & 7) ? blockIdx.x : (blockIdx.x & 7) * per + (blockIdx.x >> 3);
   uint32_t* slots = reinterpret_cast<uint32_t*>(tiles + (size_t)blockIdx.x * 2 * kSlotBytes);
   // every workgroup runs the same number of rounds and every wavefront goes through every round (barriers)
-  const uint64_t nrounds = (p.nframes + kRoundFrames - 1) / kRoundFrames;
+  const uint64_t nrounds = (p.nframes + kRF - 1) / kRF;
   const uint64_t rounds = (nrounds + gridDim.x - 1) / gridDim.x;
 
   auto first_frame = [&](uint64_t it) -> uint64_t {  // of this wavefront in iteration `it` (>= nframes: none)
-    const uint64_t round = it >> 3;
+    const uint64_t round = it / kRIters;
     if (round >= rounds) return p.nframes;
-    return (round * gridDim.x + vb) * kRoundFrames + 32 * (it & 7) + 2 * wave;
+    return (round * gridDim.x + vb) * kRF + 32 * (it % kRIters) + 2 * wave;
   };
   constexpr int kRaw = HOP64 > 0 ? 32 + HOP64 : 64;
   float raw[kRaw];
@@ -506,18 +511,25 @@ __global__ __launch_bounds__(kWaves * 64) void stft2048_rgba_kernel(StftParams p
     }
   };
   fetch(first_frame(0));
-  uint4 fq[2] = {};
-  for (uint64_t it = 0; it < (rounds + 1) * 8; ++it) {
-    const uint64_t round = it >> 3;
-    const int i = (int)(it & 7);
+  uint4 fq[kFPI][2] = {};
+  // quarter j of iteration i: part and reader unit
+  auto part_of = [](int i, int j) { return kFPI == 1 ? (i & 3) : i; };
+  auto unit_of = [&](int i, int j) { return kFPI == 1 ? wave + 16 * (i >> 2) : wave + 16 * j; };
+  for (uint64_t it = 0; it < (rounds + 1) * kRIters; ++it) {
+    const uint64_t round = it / kRIters;
+    const int i = (int)(it % kRIters);
     const uint64_t f0 = first_frame(it);
     uint32_t* slot = slots + (round & 1) * (kSlotBytes / 4);
     // (the empty asm is a use of the loaded registers: the wait for them lands here, before the image stores)
 #pragma unroll
     for (int a = 0; a < kRaw; ++a) asm volatile("" : "+v"(raw[a]));
     if (round > 0) {
-      const uint64_t frame0 = ((round - 1) * gridDim.x + vb) * kRoundFrames;
-      if (frame0 < p.nframes) rgba_flush::flush_quarter_store(p, fq, p.lut, frame0, i & 3, wave + 16 * (i >> 2), lane);
+      const uint64_t frame0 = ((round - 1) * gridDim.x + vb) * kRF;
+      if (frame0 < p.nframes) {
+#pragma unroll
+        for (int j = 0; j < kFPI; ++j)
+          rgba_flush::flush_quarter_store<kRF>(p, fq[j], p.lut, frame0, part_of(i, j), unit_of(i, j), lane);
+      }
     }
     if (f0 < p.nframes) {  // wave-uniform
       float re[32], im[32];
@@ -560,17 +572,19 @@ __global__ __launch_bounds__(kWaves * 64) void stft2048_rgba_kernel(StftParams p
 #undef SONO_BIN
           const int kq = 128 * P + le + 64 * q;
           if (4 * kq >= (int)p.bin_lo && 4 * kq < (int)p.bin_hi)
-            reinterpret_cast<uint2*>(slot)[rgba_flush::slot_cell(kq, fg) * 2 + (wave & 1)] = make_uint2(shifted ? wb : wa, wb);
+            reinterpret_cast<uint2*>(slot)[rgba_flush::slot_cell<kRF>(kq, fg) * 2 + (wave & 1)] = make_uint2(shifted ? wb : wa, wb);
         }
         wave_sync();  // the buffer is rewritten by the next half / the next iteration's transpose
       }
     }
     fetch(first_frame(it + 1));
-    if (i == 7) __syncthreads();  // this round's slot is complete and everyone is done reading the other one
-    const uint64_t nround = (it + 1) >> 3;
+    if (i == kRIters - 1) __syncthreads();  // this round's slot is complete and everyone is done reading the other one
+    const uint64_t nround = (it + 1) / kRIters;
     if (nround > 0 && nround <= rounds) {
-      const int ni = (int)((it + 1) & 7);
-      rgba_flush::flush_quarter_load(fq, slots + ((nround - 1) & 1) * (kSlotBytes / 4), ni & 3, wave + 16 * (ni >> 2), lane);
+      const int ni = (int)((it + 1) % kRIters);
+#pragma unroll
+      for (int j = 0; j < kFPI; ++j)
+        rgba_flush::flush_quarter_load<kRF>(fq[j], slots + ((nround - 1) & 1) * (kSlotBytes / 4), part_of(ni, j), unit_of(ni, j), lane);
     }
   }
 }
@@ -626,7 +640,7 @@ int launch_stft_fast2048(const StftParams& p, void* stream_v) {
   const bool plugin = p.scale_mode == SONO_SCALE_PLUGIN_DB, i16 = p.in_kind == SONO_IN_I16, feat = p.out_kind == SONO_OUT_FEATURES;
   const bool tab = p.fast_mode == 2;
   if (rgba) {
-    const uint64_t nr = (p.nframes + rgba_flush::kRoundFrames - 1) / rgba_flush::kRoundFrames;
+    const uint64_t nr = (p.nframes + kRF - 1) / kRF;
     const uint32_t rgrid = (uint32_t)(nr < (uint64_t)cus ? nr : (uint64_t)cus);
     uint8_t* tiles = reinterpret_cast<uint8_t*>(p.tile_scratch);
 #define SONO_R2048(PL, In, H)                                                                                   \
