@@ -376,11 +376,17 @@ __global__ __launch_bounds__(kWaves * 64) void stft512_kernel(StftParams p, Fast
 // the end of the iteration before, so that the only wait on the memory counter comes before the image stores.
 // At the end of the recording a block of four frames is shifted back (loads stay in bounds) and the lane moves
 // the frames it owns to the front of its slot cell.
+#ifndef SONO_RF512
+#define SONO_RF512 256
+#endif
+constexpr int kRF = SONO_RF512;     // frames per workgroup round: 256 (two iterations) or 128 (one, a barrier per iteration: measured no faster)
+constexpr int kRIters = kRF / 128;  // iterations per round
+constexpr int kFPI = 4 / kRIters;   // quarters written out per iteration
+
 template <bool PLUGIN, typename In, int HOP32, bool TABLE>
 __global__ __launch_bounds__(kWaves * 64) void stft512_rgba_kernel(StftParams p, FastScale fs, const float2* __restrict__ tw_table,
                                                                    uint8_t* __restrict__ tiles) {
   using rgba_flush::kRoundBytes;
-  using rgba_flush::kRoundFrames;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float2* tw_lds = reinterpret_cast<float2*>(smem);
   float* win_lds = reinterpret_cast<float*>(smem + kTwBytes);
@@ -412,14 +418,14 @@ __global__ __launch_bounds__(kWaves * 64) void stft512_rgba_kernel(StftParams p,
   const uint32_t vb = (gridDim.x & 7) ? blockIdx.x : (blockIdx.x & 7) * per + (blockIdx.x >> 3);
   uint32_t* slots = reinterpret_cast<uint32_t*>(tiles + (size_t)blockIdx.x * 2 * kRoundBytes);
   // every workgroup runs the same number of rounds and every wavefront goes through every round (barriers)
-  const uint64_t nrounds = (p.nframes + kRoundFrames - 1) / kRoundFrames;
+  const uint64_t nrounds = (p.nframes + kRF - 1) / kRF;
   const uint64_t rounds = (nrounds + gridDim.x - 1) / gridDim.x;
 
   // first frame of this half-wavefront in iteration `it` (>= nframes: nothing of its own)
   auto first_frame = [&](uint64_t it) -> uint64_t {
-    const uint64_t round = it >> 1;
+    const uint64_t round = it / kRIters;
     if (round >= rounds) return p.nframes;
-    return (round * gridDim.x + vb) * kRoundFrames + 128 * (it & 1) + 8 * wave + 4 * h;
+    return (round * gridDim.x + vb) * kRF + 128 * (it % kRIters) + 8 * wave + 4 * h;
   };
   constexpr int kRaw = HOP32 > 0 ? 16 + 3 * HOP32 : 64;
   float raw[kRaw];
@@ -441,24 +447,24 @@ __global__ __launch_bounds__(kWaves * 64) void stft512_rgba_kernel(StftParams p,
     }
   };
   fetch(first_frame(0));
-  uint4 fqa[2] = {}, fqb[2] = {};  // slot reads of the two quarters the iteration writes out
-  for (uint64_t it = 0; it < (rounds + 1) * 2; ++it) {
-    const uint64_t round = it >> 1;
-    const int i = (int)(it & 1);
+  uint4 fq[kFPI][2] = {};  // slot reads of the quarters the iteration writes out
+  for (uint64_t it = 0; it < (rounds + 1) * kRIters; ++it) {
+    const uint64_t round = it / kRIters;
+    const int i = (int)(it % kRIters);
     const uint64_t f0 = first_frame(it);
     uint32_t* slot = slots + (round & 1) * (kRoundBytes / 4);
     // (the empty asm is a use of the loaded registers: the wait for them lands here, before the image stores)
 #pragma unroll
     for (int a = 0; a < kRaw; ++a) asm volatile("" : "+v"(raw[a]));
     if (round > 0) {
-      const uint64_t frame0 = ((round - 1) * gridDim.x + vb) * kRoundFrames;
+      const uint64_t frame0 = ((round - 1) * gridDim.x + vb) * kRF;
       if (frame0 < p.nframes) {
-        rgba_flush::flush_quarter_store(p, fqa, lut_lds, frame0, 2 * i, wave, lane);
-        rgba_flush::flush_quarter_store(p, fqb, lut_lds, frame0, 2 * i + 1, wave, lane);
+#pragma unroll
+        for (int j = 0; j < kFPI; ++j) rgba_flush::flush_quarter_store<kRF>(p, fq[j], lut_lds, frame0, kFPI * i + j, wave, lane);
       }
     }
     // wave-uniform: does this wavefront have a frame in this iteration?
-    const uint64_t wave_f0 = round < rounds ? (round * gridDim.x + vb) * kRoundFrames + 128 * i + 8 * wave : p.nframes;
+    const uint64_t wave_f0 = round < rounds ? (round * gridDim.x + vb) * kRF + 128 * i + 8 * wave : p.nframes;
     if (wave_f0 < p.nframes) {
       float re[32], im[32];
       {
@@ -522,18 +528,18 @@ __global__ __launch_bounds__(kWaves * 64) void stft512_rgba_kernel(StftParams p,
         }
         const int kq = 32 * P + le;
         if (4 * kq >= (int)p.bin_lo && 4 * kq < (int)p.bin_hi)
-          reinterpret_cast<uint4*>(slot)[rgba_flush::slot_cell(kq, fg)] = make_uint4(w4[0], w4[1], w4[2], w4[3]);
+          reinterpret_cast<uint4*>(slot)[rgba_flush::slot_cell<kRF>(kq, fg)] = make_uint4(w4[0], w4[1], w4[2], w4[3]);
         wave_sync();  // the buffer is rewritten by the next half / the next iteration's transpose
       }
     }
     fetch(first_frame(it + 1));  // unconditional: a half with nothing of its own reads the last block of the recording
-    if (i == 1) __syncthreads();  // this round's slot is complete and everyone is done reading the other one
-    const uint64_t nround = (it + 1) >> 1;
+    if (i == kRIters - 1) __syncthreads();  // this round's slot is complete and everyone is done reading the other one
+    const uint64_t nround = (it + 1) / kRIters;
     if (nround > 0 && nround <= rounds) {
       const uint32_t* prev = slots + ((nround - 1) & 1) * (kRoundBytes / 4);
-      const int ni = (int)((it + 1) & 1);
-      rgba_flush::flush_quarter_load(fqa, prev, 2 * ni, wave, lane);
-      rgba_flush::flush_quarter_load(fqb, prev, 2 * ni + 1, wave, lane);
+      const int ni = (int)((it + 1) % kRIters);
+#pragma unroll
+      for (int j = 0; j < kFPI; ++j) rgba_flush::flush_quarter_load<kRF>(fq[j], prev, kFPI * ni + j, wave, lane);
     }
   }
 }
@@ -590,7 +596,7 @@ int launch_stft_fast512(const StftParams& p, void* stream_v) {
   const bool plugin = p.scale_mode == SONO_SCALE_PLUGIN_DB, i16 = p.in_kind == SONO_IN_I16, feat = p.out_kind == SONO_OUT_FEATURES;
   const bool tab = p.fast_mode == 2;
   if (rgba) {
-    const uint64_t nr = (p.nframes + rgba_flush::kRoundFrames - 1) / rgba_flush::kRoundFrames;
+    const uint64_t nr = (p.nframes + kRF - 1) / kRF;
     const uint32_t rgrid = (uint32_t)(nr < (uint64_t)cus ? nr : (uint64_t)cus);
     uint8_t* tiles = reinterpret_cast<uint8_t*>(p.tile_scratch);
     const int lds = kLdsBytes + rgba_flush::kLutBytes;
