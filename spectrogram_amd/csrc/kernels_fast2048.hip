@@ -463,14 +463,25 @@ constexpr int kRIters = kRF / 32;       // iterations per round
 constexpr int kFPI = 8 / kRIters;       // quarters a wavefront writes out per iteration (32 units x 4 quarters per round)
 constexpr int kSlotBytes = 1024 * kRF;
 
-template <bool PLUGIN, typename In, int HOP64>
+template <bool PLUGIN, typename In, int HOP64, bool TABLE>
 __global__ __launch_bounds__(kWaves * 64) void stft2048_rgba_kernel(StftParams p, FastScale fs, const float2* __restrict__ tw_table,
                                                                     uint8_t* __restrict__ tiles) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float2* tw_lds = reinterpret_cast<float2*>(smem);
   float* win_lds = reinterpret_cast<float*>(smem + kTwBytes);
+  const float2* __restrict__ tw_flat = reinterpret_cast<const float2*>(p.twiddles);
   for (int i = threadIdx.x; i < 2048; i += kWaves * 64) {
-    tw_lds[i] = tw_table[i];
+    if constexpr (TABLE) {
+      const int r = i >> 5, k = i & 31;  // rows 0..30: stage T = 32t, factor 32j + k (r = t-1+j); rows 31..62: T = 1024, 32m + k
+      if (r < 31) {
+        const int t = 1 << (31 - __builtin_clz(r + 1)), j = r + 1 - t;
+        tw_lds[i] = tw_flat[32 * t - 1 + 32 * j + k];
+      } else if (r < 63) {
+        tw_lds[i] = tw_flat[1023 + 32 * (r - 31) + k];
+      }
+    } else {
+      tw_lds[i] = tw_table[i];
+    }
     win_lds[i] = p.window[i];
   }
   __syncthreads();
@@ -539,7 +550,7 @@ __global__ __launch_bounds__(kWaves * 64) void stft2048_rgba_kernel(StftParams p
         re[brev5(a)] = raw[a] * w;
         im[brev5(a)] = raw[a + (HOP64 > 0 ? HOP64 : 32)] * w;
       }
-      transform2048<false>(re, im, tw_lds, nullptr, plane, lane);
+      transform2048<TABLE>(re, im, tw_lds, tw_flat, plane, lane);
 
       int le = lane;
       asm volatile("" : "+v"(le));  // (keeps loop-invariant epilogue addresses out of registers the transforms need)
@@ -548,7 +559,7 @@ __global__ __launch_bounds__(kWaves * 64) void stft2048_rgba_kernel(StftParams p
       const int fg = 8 * i + (wave >> 1);
 #pragma unroll
       for (int P = 0; P < 2; ++P) {
-        epilogue_cells(P, re, im, cell, kappa);
+        if constexpr (TABLE) epilogue_cells_table(P, re, im, cell, le); else epilogue_cells(P, re, im, cell, kappa);
         wave_sync();
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
@@ -615,7 +626,8 @@ bool fast2048_available(const StftParams& p) {
 // The image output needs whole 16-bin groups, the flipped full-height row mapping, a colour table and the scratch
 // buffer (fast_rgba_scratch_bytes()).
 bool fast2048_rgba_available(const StftParams& p) {
-  if (p.n != 2048 || p.fast_mode != 1 || !p.fast_table || p.nframes < 2) return false;
+  if (p.n != 2048 || p.nframes < 2) return false;
+  if (!((p.fast_mode == 1 && p.fast_table) || (p.fast_mode == 2 && p.twiddles))) return false;
   if ((p.bin_lo & 15) || (p.bin_hi & 15) || p.bin_lo >= p.bin_hi) return false;
   if (p.row_of_bin0 != (int32_t)p.bin_hi - 1) return false;
   return p.width != 0 && p.width <= ((uint64_t)1 << 24) && p.lut;
@@ -645,7 +657,11 @@ int launch_stft_fast2048(const StftParams& p, void* stream_v) {
     uint8_t* tiles = reinterpret_cast<uint8_t*>(p.tile_scratch);
 #define SONO_R2048(PL, In, H)                                                                                   \
   do {                                                                                                          \
-    auto kern = stft2048_rgba_kernel<PL, In, H>;                                                                \
+    if (tab) SONO_R2048_T(PL, In, H, true); else SONO_R2048_T(PL, In, H, false);                                \
+  } while (0)
+#define SONO_R2048_T(PL, In, H, T)                                                                              \
+  do {                                                                                                          \
+    auto kern = stft2048_rgba_kernel<PL, In, H, T>;                                                             \
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,    \
                             kLdsBytes) != hipSuccess)                                                           \
       return SONO_ERR_DEVICE;                                                                                   \
@@ -658,6 +674,7 @@ int launch_stft_fast2048(const StftParams& p, void* stream_v) {
     if (plugin) { if (i16) SONO_R2048_H(true, int16_t); else SONO_R2048_H(true, float); }
     else { if (i16) SONO_R2048_H(false, int16_t); else SONO_R2048_H(false, float); }
 #undef SONO_R2048_H
+#undef SONO_R2048_T
 #undef SONO_R2048
     return hipGetLastError() == hipSuccess ? SONO_OK : SONO_ERR_DEVICE;
   }
