@@ -209,6 +209,11 @@ __global__ __launch_bounds__(kMaxWaves * 64, 4) void stft1024_u8_kernel(StftPara
       if (r < 31) {
         const int half = 1 << (31 - __builtin_clz(r + 1)), j = r + 1 - half;
         tw_lds[i] = tw_flat[32 * half - 1 + 32 * j + lane_p];
+      } else if (lane_p < 31) {
+        // last row: the 31 factors of the first pass (stages T = 1..16, flat positions 0..30).  Read from LDS they
+        // cost a broadcast read each; read from global memory they would be vector loads (the compiler cannot
+        // prove them unclobbered) that wait behind the image stores on the same counter.
+        tw_lds[i] = tw_flat[lane_p];
       }
     } else {
       tw_lds[i] = tw_table[i];
@@ -346,7 +351,7 @@ __global__ __launch_bounds__(kMaxWaves * 64, 4) void stft1024_u8_kernel(StftPara
     // k1 -> lane k1, register l; the real and the imaginary plane go through the same LDS buffer one
     // after the other
     if constexpr (TABLE) {
-      fft32_table<true>(re, im, [&](int half, int j) { return tw_flat[half - 1 + j]; });  // stages T = 1..16, wave-uniform
+      fft32_table<true>(re, im, [&](int half, int j) { return tw_lds[31 * 32 + half - 1 + j]; });  // stages T = 1..16, wave-uniform
     } else {
       fft32(re, im);  // Y_l[k1]
 #pragma unroll

@@ -180,7 +180,7 @@ __device__ __forceinline__ void transform2048(float (&re)[32], float (&im)[32], 
                                               float* plane, int lane) {
   const int k1r = lane & 31, hb = lane >> 5;
   if constexpr (TABLE) {
-    fft32_table<true>(re, im, [&](int half, int j) { return tw_flat[half - 1 + j]; });
+    fft32_table<true>(re, im, [&](int half, int j) { return tw_lds[63 * 32 + half - 1 + j]; });
   } else {
     fft32(re, im);  // Y_l[k1]
 #pragma unroll
@@ -323,6 +323,8 @@ __global__ __launch_bounds__(kWaves * 64) void stft2048_kernel(StftParams p, Fas
         tw_lds[i] = tw_flat[32 * t - 1 + 32 * j + k];
       } else if (r < 63) {
         tw_lds[i] = tw_flat[1023 + 32 * (r - 31) + k];
+      } else if (k < 31) {
+        tw_lds[i] = tw_flat[k];  // last row: the 31 factors of the first pass (broadcast reads instead of global loads)
       }
     } else {
       tw_lds[i] = tw_table[i];
@@ -478,6 +480,8 @@ __global__ __launch_bounds__(kWaves * 64) void stft2048_rgba_kernel(StftParams p
         tw_lds[i] = tw_flat[32 * t - 1 + 32 * j + k];
       } else if (r < 63) {
         tw_lds[i] = tw_flat[1023 + 32 * (r - 31) + k];
+      } else if (k < 31) {
+        tw_lds[i] = tw_flat[k];  // last row: the 31 factors of the first pass (broadcast reads instead of global loads)
       }
     } else {
       tw_lds[i] = tw_table[i];

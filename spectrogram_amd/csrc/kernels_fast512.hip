@@ -150,7 +150,7 @@ template <bool TABLE>
 __device__ __forceinline__ void transform512(float (&re)[32], float (&im)[32], const float2* tw_lds,
                                              const float2* __restrict__ tw_flat, float* plane, int l) {
   if constexpr (TABLE) {
-    dit32_table<4, true>(re, im, [&](int half, int j) { return tw_flat[half - 1 + j]; });  // stages T = 1..8, wave-uniform
+    dit32_table<4, true>(re, im, [&](int half, int j) { return tw_lds[31 * 16 + half - 1 + j]; });  // stages T = 1..8, wave-uniform
   } else {
     dit32<4>(re, im);  // Y_l[k1] of A in registers k1, of B in 16 + k1
 #pragma unroll
@@ -231,6 +231,8 @@ __global__ __launch_bounds__(kWaves * 64) void stft512_kernel(StftParams p, Fast
       if (r < 31) {
         const int t = 1 << (31 - __builtin_clz(r + 1)), j = r + 1 - t;
         tw_lds[i] = tw_flat[16 * t - 1 + 16 * j + kk];
+      } else if (kk < 15) {
+        tw_lds[i] = tw_flat[kk];  // last row: the 15 factors of the first pass (broadcast reads instead of global loads)
       }
     } else {
       tw_lds[i] = tw_table[i];
@@ -398,6 +400,8 @@ __global__ __launch_bounds__(kWaves * 64) void stft512_rgba_kernel(StftParams p,
       if (r < 31) {
         const int t = 1 << (31 - __builtin_clz(r + 1)), j = r + 1 - t;
         tw_lds[i] = tw_flat[16 * t - 1 + 16 * j + kk];
+      } else if (kk < 15) {
+        tw_lds[i] = tw_flat[kk];  // last row: the 15 factors of the first pass (broadcast reads instead of global loads)
       }
     } else {
       tw_lds[i] = tw_table[i];
