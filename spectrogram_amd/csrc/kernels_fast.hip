@@ -403,6 +403,10 @@ __global__ __launch_bounds__(kMaxWaves * 64, 4) void stft1024_u8_kernel(StftPara
     const float mag_scale = PLUGIN ? 1.0f / (float)kNPoints : 0.5f;
     float best_a = -1.0f, best_b = -1.0f;  // FEAT: this lane's largest |X|^2 so far and its bin
     int kbest_a = (int)p.bin_lo, kbest_b = (int)p.bin_lo;
+    int lq = l;
+    // (FEAT: an opaque copy keeps the loop-invariant bin numbers and band tests out of registers the transform needs;
+    // hoisted, they were spilled and every reload waited on the memory counter)
+    if constexpr (FEAT) asm volatile("" : "+v"(lq));
 #pragma unroll
     for (int P = 0; P < 2; ++P) {
 #pragma unroll
@@ -417,7 +421,7 @@ __global__ __launch_bounds__(kMaxWaves * 64, 4) void stft1024_u8_kernel(StftPara
       uint32_t wa2[2], wb2[2];
 #pragma unroll
       for (int g = 0; g < 2; ++g) {
-        const int idx = 4 * (l + 32 * g);
+        const int idx = 4 * (lq + 32 * g);
         const int k = 256 * P + idx;
         const float4 z01 = *reinterpret_cast<const float4*>(lbuf + idx);
         const float4 z23 = *reinterpret_cast<const float4*>(lbuf + idx + 2);
