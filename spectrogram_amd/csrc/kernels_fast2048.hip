@@ -373,7 +373,11 @@ __global__ __launch_bounds__(kWaves * 64) void stft2048_kernel(StftParams p, Fas
         }
       }
     }
-    transform2048<TABLE>(re, im, tw_lds, tw_flat, plane, lane);
+    int lt = lane;
+    // (TABLE: an opaque copy keeps the transform's loop-invariant LDS addresses out of registers it needs itself;
+    // hoisted, they were spilled and every reload waited on the memory counter)
+    if constexpr (TABLE) asm volatile("" : "+v"(lt));
+    transform2048<TABLE>(re, im, tw_lds, tw_flat, plane, lt);
 
     // Epilogue in two halves of 512 bins.
     int le = lane;
@@ -554,7 +558,9 @@ __global__ __launch_bounds__(kWaves * 64) void stft2048_rgba_kernel(StftParams p
         re[brev5(a)] = raw[a] * w;
         im[brev5(a)] = raw[a + (HOP64 > 0 ? HOP64 : 32)] * w;
       }
-      transform2048<TABLE>(re, im, tw_lds, tw_flat, plane, lane);
+      int lt = lane;
+      if constexpr (TABLE) asm volatile("" : "+v"(lt));  // (as in the index kernel)
+      transform2048<TABLE>(re, im, tw_lds, tw_flat, plane, lt);
 
       int le = lane;
       asm volatile("" : "+v"(le));  // (keeps loop-invariant epilogue addresses out of registers the transforms need)
