@@ -388,7 +388,9 @@ __global__ __launch_bounds__(kMaxWaves * 64, 4) void stft1024_u8_kernel(StftPara
     }
     wave_sync();
     if constexpr (TABLE) {
-      fft32_table<false>(re, im, [&](int half, int j) { return tw_lds[(half - 1 + j) * 32 + l]; });  // stages T = 32..512
+      int lt = l;
+      asm volatile("" : "+v"(lt));  // (keeps 31 loop-invariant LDS addresses out of registers: hoisted, some were spilled)
+      fft32_table<false>(re, im, [&](int half, int j) { return tw_lds[(half - 1 + j) * 32 + lt]; });  // stages T = 32..512
     } else {
       fft32(re, im);  // X[l + 32*k2]
     }
