@@ -254,15 +254,30 @@ uint64_t sono_out_bytes(const sono_ctx* ctx, uint64_t n_samples);
  * through context-owned device memory.  Synchronous: the result is complete on return. */
 int sono_stft(sono_ctx* ctx, const void* pcm, uint64_t n_samples, void* out, uint64_t out_capacity_bytes, int mem);
 
-/* Same, device pointers only, enqueued on the context's stream without waiting. */
+/* Same, device pointers only, enqueued on the context's stream without waiting.  Allocates nothing and never
+ * synchronises: every device buffer it needs besides the caller's (tables, the scratch of the RGBA routes) was
+ * sized by sono_create / sono_set_tables / sono_set_filterbank; an RGBA route whose colour indices do not fit the
+ * context's scratch works through it in chunks of frames. */
 int sono_stft_async(sono_ctx* ctx, const void* pcm_dev, uint64_t n_samples, void* out_dev, uint64_t out_capacity_bytes);
 int sono_wait(sono_ctx* ctx);
+
+/* Kernels that the most recent transform call on this context enqueued, e.g. "stft1024_u8_kernel<roots>:rgba" or
+ * "stft_mw_kernel<4096>:u8 + colorize_kernel" ("" before the first call).  A context whose size, arithmetic,
+ * tables or band no specialised kernel serves reads "stft_general_kernel<...>", which is about ten times slower;
+ * hosts print this so that the fall-back is visible.  No counterpart in the reference. */
+const char* sono_kernel_route(const sono_ctx* ctx);
+
+/* Sizes the context's staging buffers for recordings of up to n_samples, so that later sono_stft_host_async calls
+ * of that size or less do not allocate (an allocation waits for the whole device).  May allocate and wait itself.
+ * No counterpart in the reference. */
+int sono_reserve(sono_ctx* ctx, uint64_t n_samples);
 
 /* Host pointers, enqueued without waiting: copy in, transform, copy out on the context's stream, through
  * the context's staging buffers (so: one transform in flight per context; a batch host cycles over a
  * few contexts to overlap the copies of one file with the transform of another).  The copies only run
- * asynchronously from page-locked memory (sono_host_malloc).  No counterpart in the reference (its
- * worker gets a transferred ArrayBuffer, main.js:1417). */
+ * asynchronously from page-locked memory (sono_host_malloc).  The staging buffers grow -- which waits for
+ * the device -- only when a call is larger than every earlier one and than sono_reserve's size.  No
+ * counterpart in the reference (its worker gets a transferred ArrayBuffer, main.js:1417). */
 int sono_stft_host_async(sono_ctx* ctx, const void* pcm_host, uint64_t n_samples, void* out_host, uint64_t out_capacity_bytes);
 void* sono_host_malloc(uint64_t bytes);
 int sono_host_free(void* p);

@@ -109,6 +109,8 @@ SYMBOLS = {
     "sono_stft": (C.c_int, [_VP, _VP, C.c_uint64, _VP, C.c_uint64, C.c_int]),
     "sono_stft_async": (C.c_int, [_VP, _VP, C.c_uint64, _VP, C.c_uint64]),
     "sono_wait": (C.c_int, [_VP]),
+    "sono_kernel_route": (C.c_char_p, [_VP]),
+    "sono_reserve": (C.c_int, [_VP, C.c_uint64]),
     "sono_resample": (C.c_int, [_VP, _VP, C.c_uint64, C.c_uint32, C.c_uint64, _VP, C.c_int]),
     "sono_resample_cols": (C.c_int, [_VP, _VP, C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint64, C.c_uint64, _VP, C.c_int]),
     "sono_colorize": (C.c_int, [_VP, _VP, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, _VP, C.c_int]),

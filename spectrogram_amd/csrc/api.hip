@@ -41,8 +41,18 @@ struct sono_ctx {
   uint64_t d_out_bytes = 0;
   void* d_aux = nullptr;
   uint64_t d_aux_bytes = 0;
+  // facts about the tables that choose the kernel; recomputed whenever a table changes (refresh_routes)
+  uint32_t fast_mode = 0;   // StftParams::fast_mode
+  bool mw_ok = false;       // StftParams::mw_ok
+  bool pair_exact = false;  // StftParams::pair_exact
+  std::string route;        // kernels of the most recent transform call (sono_kernel_route)
   std::string err;
 };
+
+static thread_local const char* t_kernel = "";
+namespace sono {
+void note_kernel(const char* name) { t_kernel = name; }
+}
 
 static thread_local std::string g_create_error;
 
@@ -95,6 +105,8 @@ static int upload_tables(sono_ctx* c) {
   }
   return SONO_OK;
 }
+
+static int refresh_routes(sono_ctx* c);
 
 extern "C" {
 
@@ -208,6 +220,11 @@ sono_ctx* sono_create(int device, const sono_config* cfg) {
     if ((e = hipMemcpy(c->d_fast, t.data(), sizeof(float) * t.size(), hipMemcpyHostToDevice)) != hipSuccess)
       return bail("hipMemcpy(fast table)", e);
   }
+  if (refresh_routes(c) != SONO_OK) {
+    g_create_error = c->err;
+    sono_destroy(c);
+    return nullptr;
+  }
   return c;
 }
 
@@ -262,7 +279,8 @@ int sono_set_tables(sono_ctx* c, const float* window, const double* tw_cos, cons
     std::memcpy(c->h_sin.data(), tw_sin, sizeof(double) * (n - 1));
     c->host_twiddles = true;
   }
-  return upload_tables(c);
+  int rc = upload_tables(c);
+  return rc != SONO_OK ? rc : refresh_routes(c);
 }
 
 int sono_set_filterbank(sono_ctx* c, const int32_t* bin, const double* w0, const double* w1) {
@@ -274,7 +292,7 @@ int sono_set_filterbank(sono_ctx* c, const int32_t* bin, const double* w0, const
     if (c->d_fb_w) HIP_TRY(c, hipFree(c->d_fb_w));
     c->d_fb_bin = nullptr;
     c->d_fb_w = nullptr;
-    return SONO_OK;
+    return refresh_routes(c);
   }
   if (!w0 || !w1) return fail(c, SONO_ERR_ARG, "filter bank weights missing");
   if (c->cfg.scale_mode != SONO_SCALE_PLUGIN_DB) return fail(c, SONO_ERR_ARG, "a filter bank needs the plugin scale mode");
@@ -284,7 +302,7 @@ int sono_set_filterbank(sono_ctx* c, const int32_t* bin, const double* w0, const
   HIP_TRY(c, hipMemcpy(c->d_fb_bin, bin, sizeof(int32_t) * half, hipMemcpyHostToDevice));
   HIP_TRY(c, hipMemcpy(c->d_fb_w, w0, sizeof(double) * half, hipMemcpyHostToDevice));
   HIP_TRY(c, hipMemcpy(c->d_fb_w + half, w1, sizeof(double) * half, hipMemcpyHostToDevice));
-  return SONO_OK;
+  return refresh_routes(c);
 }
 
 int sono_geometry_of(const sono_ctx* c, uint64_t L, sono_geometry* out) {
@@ -305,8 +323,8 @@ uint64_t sono_out_bytes(const sono_ctx* c, uint64_t L) {
 
 static uint64_t in_bytes(const sono_ctx* c, uint64_t L) { return L * (c->cfg.in_kind == SONO_IN_I16 ? 2 : 4); }
 
-// Which flavour of the fast 1024-point kernel serves this context (StftParams::fast_mode).
-static uint32_t fast_mode_of(const sono_ctx* c) {
+// Which flavour of the fast kernels serves this context (StftParams::fast_mode).
+static uint32_t compute_fast_mode(const sono_ctx* c) {
   const uint32_t fn = c->cfg.fft_n;
   if (c->cfg.arith != SONO_ARITH_FAST_F32 || (fn != 1024 && fn != 512 && fn != 2048) || c->d_fb_bin) return 0;
   if (c->cfg.twiddle_mode == SONO_TW_ACCURATE && !c->host_twiddles) return c->d_fast ? 1 : 0;
@@ -315,7 +333,6 @@ static uint32_t fast_mode_of(const sono_ctx* c) {
     if (c->h_cos[T - 1] != 1.0 || c->h_sin[T - 1] != 0.0) return 0;
   return 2;
 }
-static bool fast_eligible(const sono_ctx* c) { return fast_mode_of(c) != 0; }
 // Largest deviation of the twiddle table from conjugate symmetry, |w[T-j] + conj(w[j])| over every stage of half
 // size T (StftParams::pair_exact).
 static double table_asymmetry(const sono_ctx* c) {
@@ -329,8 +346,8 @@ static double table_asymmetry(const sono_ctx* c) {
     }
   return worst;
 }
-// The 2048/4096-point kernel takes any twiddle table whose stages start with the factor (1, 0).
-static bool mw_eligible(const sono_ctx* c) {
+// The 512/2048/4096-point three-pass kernel takes any twiddle table whose stages start with the factor (1, 0).
+static bool compute_mw_ok(const sono_ctx* c) {
   if (c->cfg.arith != SONO_ARITH_FAST_F32 || (c->cfg.fft_n != 512 && c->cfg.fft_n != 2048 && c->cfg.fft_n != 4096) || c->d_fb_bin)
     return false;
   for (uint32_t T = 1; T < c->cfg.fft_n; T <<= 1)
@@ -338,8 +355,129 @@ static bool mw_eligible(const sono_ctx* c) {
   return true;
 }
 
-int sono_stft_async(sono_ctx* c, const void* pcm, uint64_t L, void* out, uint64_t cap) {
-  if (!c) return SONO_ERR_ARG;
+// Default size of the RGBA index-chunk buffer when the context cannot write the image from the transform kernel.
+constexpr uint64_t kDefaultChunkBytes = (uint64_t)32 << 20;
+constexpr uint64_t kMaxChunkBytes = (uint64_t)96 << 20;
+
+// Recomputes what the kernel choice depends on and sizes the context's RGBA scratch.  Runs in the calls that may
+// allocate and wait (sono_create, sono_set_tables, sono_set_filterbank), never in a transform call.
+static int refresh_routes(sono_ctx* c) {
+  c->fast_mode = compute_fast_mode(c);
+  c->mw_ok = compute_mw_ok(c);
+  c->pair_exact = table_asymmetry(c) <= 5e-7;
+  if (c->cfg.out_kind == SONO_OUT_RGBA8) {
+    const uint64_t want = c->fast_mode ? fast_rgba_scratch_bytes() : kDefaultChunkBytes;
+    if (c->d_aux_bytes < want) {
+      HIP_TRY(c, hipStreamSynchronize(c->stream));
+      int rc = ensure(c, &c->d_aux, &c->d_aux_bytes, want);
+      if (rc != SONO_OK) return rc;
+    }
+  }
+  return SONO_OK;
+}
+
+// Appends the kernel that the last launch_* call reported to the context's route string.
+static void note_route(sono_ctx* c, const char* suffix = nullptr) {
+  if (c->route.size() > 200) return;  // (a chunked call repeats itself)
+  std::string item = t_kernel;
+  if (suffix) item += suffix;
+  if (c->route.find(item) != std::string::npos) return;
+  if (!c->route.empty()) c->route += " + ";
+  c->route += item;
+}
+
+// Where the colour indices of the two-kernel RGBA route are parked.
+struct IndexScratch {
+  void* ptr;
+  uint64_t bytes;
+  bool single_chunk;  // sono_stft_static: the whole call must fit
+};
+
+// One frame range through the kernels.  Allocates nothing and does not wait.
+static int launch_range(sono_ctx* c, const StftParams& q, const IndexScratch& aux, bool fused_ok) {
+  if ((q.frame0 + q.nframes - 1) * q.hop + q.n > q.n_samples) return fail(c, SONO_ERR_ARG, "frame range exceeds the signal");
+  int r = 1;
+  StftParams qq = q;
+  if (!qq.lut) qq.lut = c->d_lut + 256;
+  const bool fast = c->fast_mode != 0;
+  const bool exact = c->cfg.arith == SONO_ARITH_EXACT_F64;
+  const bool rgba = q.out_kind == SONO_OUT_RGBA8;
+  if (fused_ok && fast && rgba && (fast_rgba_available(qq) || fast512_rgba_available(qq) || fast2048_rgba_available(qq))) {
+    // the fast kernel writes the image itself; its rounds go through a scratch buffer sized at set-up
+    if (!c->d_aux || c->d_aux_bytes < fast_rgba_scratch_bytes())
+      return fail(c, SONO_ERR_ARG, "the context's image scratch is missing (tables changed without sono_set_tables?)");
+    qq.tile_scratch = c->d_aux;
+    r = launch_stft_fast(qq, c->stream);
+    if (r == 1) r = launch_stft_fast512(qq, c->stream);
+    if (r == 1) r = launch_stft_fast2048(qq, c->stream);
+    if (r != SONO_OK) return fail(c, r, "kernel launch failed: %s", hipGetErrorString(hipGetLastError()));
+    note_route(c, ":rgba");
+    return SONO_OK;
+  }
+  if (rgba && q.row_of_bin0 == (int32_t)q.bin_hi - 1 && (q.nframes >= 16 || aux.single_chunk)) {
+    // RGBA in two kernels: colour indices of a chunk of frames go to a [frame][bin] buffer small enough to stay in
+    // the Infinity Cache, then a transposing LUT kernel writes the chunk's image columns.  The index kernels want
+    // whole groups of four bins, so the chunk holds the band rounded outwards and the LUT kernel takes its rows.
+    StftParams u = q;
+    u.out_kind = SONO_OUT_U8_INDEX;
+    u.bin_lo = q.bin_lo & ~3u;
+    u.bin_hi = (q.bin_hi + 3u) & ~3u;
+    u.out_bins = u.bin_hi - u.bin_lo;
+    u.out_bin0 = u.bin_lo;
+    u.lut = nullptr;
+    const bool fast_u8 = exact ? exact1024_available(u) : (fast_u8_available(u) || mw_u8_available(u) || fast);
+    if (fast_u8 || aux.single_chunk) {
+      const uint64_t nb = u.out_bins;
+      if (!aux.ptr || aux.bytes < 64 * nb)
+        return fail(c, SONO_ERR_ARG, "no index scratch for the RGBA route");
+      uint64_t chunk = (aux.bytes < kMaxChunkBytes ? aux.bytes : kMaxChunkBytes) / nb / 64 * 64;  // frames per chunk
+      if (aux.single_chunk) {
+        if (q.nframes * nb > aux.bytes)
+          return fail(c, SONO_ERR_CAPACITY, "%llu frames x %llu bins exceed the %llu-byte static index plane",
+                      (unsigned long long)q.nframes, (unsigned long long)nb, (unsigned long long)aux.bytes);
+        chunk = q.nframes;
+      }
+      for (uint64_t f = 0; f < q.nframes; f += chunk) {
+        u.frame0 = q.frame0 + f;
+        u.nframes = (q.nframes - f < chunk) ? q.nframes - f : chunk;
+        u.col0 = 0;
+        u.out = aux.ptr;
+        r = 1;
+        if (exact) {
+          r = launch_stft_exact(u, c->stream);
+          if (r == 1) r = launch_stft_general(u, true, c->stream);
+        } else if (u.nframes >= 16) {
+          if (fast) r = launch_stft_fast(u, c->stream);
+          if (r == 1 && fast) r = launch_stft_fast512(u, c->stream);
+          if (r == 1 && fast) r = launch_stft_fast2048(u, c->stream);
+          if (r == 1 && u.mw_ok) r = launch_stft_mw(u, c->stream);
+        }
+        if (r == 1) r = launch_stft_general(u, exact, c->stream);
+        if (r != SONO_OK) return fail(c, r, "kernel launch failed: %s", hipGetErrorString(hipGetLastError()));
+        note_route(c, ":u8");
+        r = launch_colorize((const uint8_t*)aux.ptr, u.nframes, (uint32_t)nb, u.bin_hi - q.bin_hi, q.bin_hi - q.bin_lo, q.lut,
+                            (uint8_t*)q.out, q.width, q.col0 + f, c->stream);
+        if (r != SONO_OK) return fail(c, r, "colorize launch failed");
+        sono::note_kernel("colorize_kernel");
+        note_route(c);
+      }
+      return SONO_OK;
+    }
+  }
+  if (fast) r = launch_stft_fast(q, c->stream);
+  if (r == 1 && fast) r = launch_stft_fast512(q, c->stream);
+  if (r == 1 && fast) r = launch_stft_fast2048(q, c->stream);
+  if (r == 1 && q.mw_ok) r = launch_stft_mw(q, c->stream);
+  if (exact) r = launch_stft_exact(q, c->stream);
+  if (r == 1) r = launch_stft_general(q, exact, c->stream);
+  if (r != SONO_OK) return fail(c, r, "kernel launch failed: %s", hipGetErrorString(hipGetLastError()));
+  note_route(c);
+  return SONO_OK;
+}
+
+// The transform of one recording on device pointers: the frames with a column of their own, then the worker's
+// wrapped last frame.  `aux` is where a two-kernel RGBA route parks its colour indices.
+static int transform(sono_ctx* c, const void* pcm, uint64_t L, void* out, uint64_t cap, const IndexScratch& aux, bool fused_ok) {
   if (!out || (!pcm && L)) return fail(c, SONO_ERR_ARG, "NULL buffer");
   sono_geometry g;
   int rc = sono_geometry_of(c, L, &g);
@@ -348,6 +486,7 @@ int sono_stft_async(sono_ctx* c, const void* pcm, uint64_t L, void* out, uint64_
   if (cap < need) return fail(c, SONO_ERR_CAPACITY, "output needs %llu bytes, capacity is %llu", (unsigned long long)need,
                               (unsigned long long)cap);
   HIP_TRY(c, hipSetDevice(c->device));
+  c->route.clear();
   const uint32_t n = c->cfg.fft_n, H = n / 2;
   const bool rgba = c->cfg.out_kind == SONO_OUT_RGBA8;
   if (rgba && g.frames < g.width)  // L < N under the worker rule: a one-column, all-zero image (createImageData)
@@ -366,9 +505,9 @@ int sono_stft_async(sono_ctx* c, const void* pcm, uint64_t L, void* out, uint64_
   p.lut = c->have_lut ? c->d_lut : nullptr;
   p.out = out;
   p.fast_table = c->d_fast;
-  p.fast_mode = fast_mode_of(c);
-  p.mw_ok = mw_eligible(c) ? 1u : 0u;
-  p.pair_exact = table_asymmetry(c) <= 5e-7 ? 1u : 0u;
+  p.fast_mode = c->fast_mode;
+  p.mw_ok = c->mw_ok ? 1u : 0u;
+  p.pair_exact = c->pair_exact ? 1u : 0u;
   p.fb_bin = c->d_fb_bin;
   p.fb_w0 = c->d_fb_w;
   p.fb_w1 = c->d_fb_w ? c->d_fb_w + n / 2 : nullptr;
@@ -381,73 +520,6 @@ int sono_stft_async(sono_ctx* c, const void* pcm, uint64_t L, void* out, uint64_
   p.out_bins = g.bins;
   p.out_bin0 = c->bin_lo;
 
-  auto launch = [&](const StftParams& q) -> int {
-    if ((q.frame0 + q.nframes - 1) * q.hop + q.n > q.n_samples) return fail(c, SONO_ERR_ARG, "frame range exceeds the signal");
-    int r = 1;
-    StftParams qq = q;
-    if (!qq.lut) qq.lut = c->d_lut + 256;
-    if (fast_eligible(c) && q.out_kind == SONO_OUT_RGBA8 && (fast_rgba_available(qq) || fast512_rgba_available(qq) || fast2048_rgba_available(qq))) {
-      // the fast kernel writes the image itself; it needs a small scratch buffer for its wavefront tiles
-      int rc2 = ensure(c, &c->d_aux, &c->d_aux_bytes, fast_rgba_scratch_bytes());
-      if (rc2 != SONO_OK) return rc2;
-      StftParams u = q;
-      u.tile_scratch = c->d_aux;
-      if (!u.lut) u.lut = c->d_lut + 256;
-      r = launch_stft_fast(u, c->stream);
-      if (r == 1) r = launch_stft_fast512(u, c->stream);
-      if (r == 1) r = launch_stft_fast2048(u, c->stream);
-      if (r != SONO_OK) return fail(c, r, "kernel launch failed: %s", hipGetErrorString(hipGetLastError()));
-      return SONO_OK;
-    }
-    const bool exact = c->cfg.arith == SONO_ARITH_EXACT_F64;
-    if ((fast_eligible(c) || q.mw_ok || exact) && q.out_kind == SONO_OUT_RGBA8 && q.row_of_bin0 == (int32_t)q.bin_hi - 1) {
-      // RGBA through the fast kernel: colour indices of a chunk of frames go to a context-owned
-      // [frame][bin] buffer small enough to stay in the Infinity Cache, then a transposing LUT
-      // kernel writes the chunk's image columns.
-      StftParams u = q;
-      u.out_kind = SONO_OUT_U8_INDEX;
-      u.out_bins = q.bin_hi - q.bin_lo;
-      u.out_bin0 = q.bin_lo;
-      if (exact ? exact1024_available(u) : (fast_u8_available(u) || mw_u8_available(u))) {
-        const uint64_t nb = u.out_bins;
-        const uint64_t chunk = ((uint64_t)96 << 20) / nb / 64 * 64;   // frames per chunk (96 MiB of indices)
-        int rc2 = ensure(c, &c->d_aux, &c->d_aux_bytes, (q.nframes < chunk ? q.nframes : chunk) * nb);
-        if (rc2 != SONO_OK) return rc2;
-        for (uint64_t f = 0; f < q.nframes; f += chunk) {
-          u.frame0 = q.frame0 + f;
-          u.nframes = (q.nframes - f < chunk) ? q.nframes - f : chunk;
-          u.col0 = 0;
-          u.out = c->d_aux;
-          if (exact) {
-            r = launch_stft_exact(u, c->stream);
-            if (r == 1) r = launch_stft_general(u, true, c->stream);
-          } else if (u.nframes < 16) {
-            r = launch_stft_general(u, false, c->stream);
-          } else {
-            r = launch_stft_fast(u, c->stream);
-            if (r == 1) r = launch_stft_fast512(u, c->stream);
-            if (r == 1) r = launch_stft_fast2048(u, c->stream);
-            if (r == 1) r = launch_stft_mw(u, c->stream);
-            if (r == 1) r = launch_stft_general(u, false, c->stream);
-          }
-          if (r != SONO_OK) return fail(c, r, "kernel launch failed: %s", hipGetErrorString(hipGetLastError()));
-          r = launch_colorize((const uint8_t*)c->d_aux, u.nframes, (uint32_t)nb, 0, (uint32_t)nb, q.lut, (uint8_t*)q.out,
-                              q.width, q.col0 + f, c->stream);
-          if (r != SONO_OK) return fail(c, r, "colorize launch failed");
-        }
-        return SONO_OK;
-      }
-    }
-    if (fast_eligible(c)) r = launch_stft_fast(q, c->stream);
-    if (r == 1 && fast_eligible(c)) r = launch_stft_fast512(q, c->stream);
-    if (r == 1 && fast_eligible(c)) r = launch_stft_fast2048(q, c->stream);
-    if (r == 1 && q.mw_ok) r = launch_stft_mw(q, c->stream);
-    if (exact) r = launch_stft_exact(q, c->stream);
-    if (r == 1) r = launch_stft_general(q, exact, c->stream);
-    if (r != SONO_OK) return fail(c, r, "kernel launch failed: %s", hipGetErrorString(hipGetLastError()));
-    return SONO_OK;
-  };
-
   // frames that have a column of their own
   const uint64_t main_frames = g.frames < g.width ? g.frames : g.width;
   p.frame0 = 0;
@@ -456,12 +528,13 @@ int sono_stft_async(sono_ctx* c, const void* pcm, uint64_t L, void* out, uint64_
   p.bin_lo = c->bin_lo;
   p.bin_hi = c->bin_hi;
   p.row_of_bin0 = (int32_t)c->bin_hi - 1;
-  rc = launch(p);
+  rc = launch_range(c, p, aux, fused_ok);
   if (rc != SONO_OK) return rc;
 
   if (g.frames > g.width) {
     // worker quirk, spectrogramWorker.js:40,59,79: frame `width` is written at x == width, i.e. at
     // column 0 one image row further down; its bin 0 falls off the end of the image.
+    const IndexScratch none = {nullptr, 0, false};
     if (rgba) {
       StftParams q = p;
       q.frame0 = g.width;
@@ -471,7 +544,7 @@ int sono_stft_async(sono_ctx* c, const void* pcm, uint64_t L, void* out, uint64_
       q.bin_hi = (c->bin_hi + 1 <= H) ? c->bin_hi + 1 : H;
       q.row_of_bin0 = (int32_t)c->bin_hi;  // one row down
       if (q.bin_lo < q.bin_hi) {
-        rc = launch(q);
+        rc = launch_range(c, q, none, false);
         if (rc != SONO_OK) return rc;
       }
     } else {
@@ -480,11 +553,38 @@ int sono_stft_async(sono_ctx* c, const void* pcm, uint64_t L, void* out, uint64_
       q.frame0 = g.width;
       q.nframes = g.frames - g.width;
       q.col0 = g.width;
-      rc = launch(q);
+      rc = launch_range(c, q, none, false);
       if (rc != SONO_OK) return rc;
     }
   }
   return SONO_OK;
+}
+
+int sono_stft_async(sono_ctx* c, const void* pcm, uint64_t L, void* out, uint64_t cap) {
+  if (!c) return SONO_ERR_ARG;
+  const IndexScratch aux = {c->d_aux, c->d_aux_bytes, false};
+  return transform(c, pcm, L, out, cap, aux, true);
+}
+
+const char* sono_kernel_route(const sono_ctx* c) { return c ? c->route.c_str() : ""; }
+
+int sono_reserve(sono_ctx* c, uint64_t L) {
+  if (!c) return SONO_ERR_ARG;
+  HIP_TRY(c, hipSetDevice(c->device));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  int rc = ensure(c, &c->d_in, &c->d_in_bytes, in_bytes(c, L));
+  if (rc != SONO_OK) return rc;
+  rc = ensure(c, &c->d_out, &c->d_out_bytes, sono_out_bytes(c, L));
+  if (rc != SONO_OK) return rc;
+  if (c->cfg.out_kind == SONO_OUT_RGBA8 && !c->fast_mode) {
+    sono_geometry g;
+    if (sono_geometry_of(c, L, &g) == SONO_OK) {
+      uint64_t want = g.frames * (((uint64_t)c->bin_hi + 3) / 4 * 4 - (c->bin_lo & ~3u));
+      if (want > kMaxChunkBytes) want = kMaxChunkBytes;
+      if (want > c->d_aux_bytes) rc = ensure(c, &c->d_aux, &c->d_aux_bytes, want);
+    }
+  }
+  return rc;
 }
 
 int sono_pcm_to_f32(sono_ctx* c, const void* src, int mem, uint32_t format_tag, uint32_t bits, uint32_t channels, uint32_t channel,

@@ -20,6 +20,7 @@
 
 #include "sono_device.h"
 #include "sono_internal.h"
+#include "sono_launch.h"
 
 namespace sono {
 namespace exact1024 {
@@ -212,22 +213,18 @@ int launch_stft_exact(const StftParams& p, void* stream_v) {
   using namespace exact1024;
   if (!exact1024_available(p)) return 1;
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_v);
-  int dev = 0, cus = 256;
-  hipDeviceProp_t prop;
-  if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
-    cus = prop.multiProcessorCount;
+  const int cus = device_cu_count();
   const uint64_t need = (p.nframes + kWaves * 2 - 1) / (kWaves * 2);
   const uint32_t grid = (uint32_t)(need < (uint64_t)cus ? need : (uint64_t)cus);
 #define SONO_LAUNCH_X(In)                                                                                        \
   do {                                                                                                           \
     auto kern = stft1024_exact_kernel<In>;                                                                       \
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,     \
-                            kLdsBytes) != hipSuccess)                                                            \
-      return SONO_ERR_DEVICE;                                                                                    \
+    SONO_GRANT_LDS(kern, kLdsBytes);                                                                             \
     hipLaunchKernelGGL(kern, dim3(grid), dim3(kWaves * 64), kLdsBytes, stream, p);                               \
   } while (0)
   if (p.in_kind == SONO_IN_I16) SONO_LAUNCH_X(int16_t); else SONO_LAUNCH_X(float);
 #undef SONO_LAUNCH_X
+  note_kernel("stft1024_exact_kernel");
   return hipGetLastError() == hipSuccess ? SONO_OK : SONO_ERR_DEVICE;
 }
 

@@ -28,6 +28,7 @@
 
 #include "sono_device.h"
 #include "sono_internal.h"
+#include "sono_launch.h"
 #include "sono_rgba_flush.h"
 
 namespace sono {
@@ -476,7 +477,7 @@ __global__ __launch_bounds__(kMaxWaves * 64, 4) void stft1024_u8_kernel(StftPara
         const auto sb = __builtin_amdgcn_permlane32_swap(wb2[0], wb2[1], false, false);
         const int kq = 64 * P + l + 32 * h;               // reader wavefront kq >> 3, its quad kq & 7
         const int fg = kTileIters * wave + (int)(it % kTileIters);  // frame group of the round
-        if (4 * kq >= (int)p.bin_lo && 4 * kq < (int)p.bin_hi)
+        if (4 * kq + 3 >= (int)p.bin_lo && 4 * kq < (int)p.bin_hi)
           reinterpret_cast<uint4*>(slot)[rgba_flush::slot_cell<kRoundFrames>(kq, fg)] = make_uint4(sa[0], sb[0], sa[1], sb[1]);
       }
       wave_sync();  // the buffer is rewritten by the next half / the next iteration's transpose
@@ -563,26 +564,18 @@ bool fast_features_available(const StftParams& p) {
   return fast_base_available(p) && !(p.bin_lo & 3) && !(p.bin_hi & 3) && p.bin_lo < p.bin_hi;
 }
 
-// The fused image output needs whole 16-bin groups, the flipped full-height row mapping and store
+// The fused image output needs the flipped full-height row mapping (any band: rows outside it are masked) and store
 // offsets (a few image rows) that fit 32 bits.
 bool fast_rgba_available(const StftParams& p) {
   if (!fast_base_available(p)) return false;
-  if ((p.bin_lo & 15) || (p.bin_hi & 15) || p.bin_lo >= p.bin_hi) return false;
+  if (p.bin_lo >= p.bin_hi) return false;
   if (p.row_of_bin0 != (int32_t)p.bin_hi - 1) return false;
   if (p.width == 0 || p.width > ((uint64_t)1 << 24) || !p.lut) return false;
   return true;
 }
 
-static int cu_count() {
-  int dev = 0;
-  hipDeviceProp_t prop;
-  if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
-    return prop.multiProcessorCount;
-  return 256;
-}
-
 // two slots per workgroup; a slot of the 2048-point kernel (1024 bins x 256 frames) is twice that of the others
-uint64_t fast_rgba_scratch_bytes() { return (uint64_t)cu_count() * 2 * 2 * fast1024::kRoundBytes; }
+uint64_t fast_rgba_scratch_bytes() { return (uint64_t)device_cu_count() * 2 * 2 * fast1024::kRoundBytes; }
 
 int launch_stft_fast(const StftParams& p, void* stream_v) {
   using namespace fast1024;
@@ -608,7 +601,7 @@ int launch_stft_fast(const StftParams& p, void* stream_v) {
   // one wavefront handles 2 pairs per iteration, or (RGBA) one 16-frame tile per 4 iterations
   const uint64_t per_wg = rgba ? (uint64_t)kRoundFrames / 2 : (uint64_t)kMaxWaves * 2;
   const uint64_t need = (npairs + per_wg - 1) / per_wg;
-  const int cus = cu_count();
+  const int cus = device_cu_count();
   const uint32_t grid = (uint32_t)(need < (uint64_t)cus ? need : (uint64_t)cus);  // persistent: one workgroup per CU
   const float2* table = reinterpret_cast<const float2*>(p.fast_table);
   uint8_t* tiles = reinterpret_cast<uint8_t*>(p.tile_scratch);
@@ -617,9 +610,7 @@ int launch_stft_fast(const StftParams& p, void* stream_v) {
 #define SONO_LAUNCH_T(PLUGIN, In, H, O, T)                                                                  \
   do {                                                                                                      \
     auto kern = stft1024_u8_kernel<PLUGIN, In, H, O, T>;                                                    \
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, \
-                            lds_total) != hipSuccess)                                                       \
-      return SONO_ERR_DEVICE;                                                                               \
+    SONO_GRANT_LDS(kern, lds_total);                                                                        \
     hipLaunchKernelGGL(kern, dim3(grid), dim3(kMaxWaves * 64), lds_total, stream, p, fs, table, tiles);     \
   } while (0)
 #define SONO_LAUNCH_O(PLUGIN, In, H, O)                                                                     \
@@ -650,6 +641,7 @@ int launch_stft_fast(const StftParams& p, void* stream_v) {
 #undef SONO_LAUNCH_H
 #undef SONO_LAUNCH_O
 #undef SONO_LAUNCH_T
+  note_kernel(tab ? "stft1024_u8_kernel<table>" : "stft1024_u8_kernel<roots>");
   return hipGetLastError() == hipSuccess ? SONO_OK : SONO_ERR_DEVICE;
 }
 

@@ -21,6 +21,7 @@
 
 #include "sono_device.h"
 #include "sono_internal.h"
+#include "sono_launch.h"
 #include "sono_rgba_flush.h"
 
 namespace sono {
@@ -592,7 +593,7 @@ __global__ __launch_bounds__(kWaves * 64) void stft2048_rgba_kernel(StftParams p
           SONO_BIN(3, z23.z, z23.w, q23.z, q23.w)
 #undef SONO_BIN
           const int kq = 128 * P + le + 64 * q;
-          if (4 * kq >= (int)p.bin_lo && 4 * kq < (int)p.bin_hi)
+          if (4 * kq + 3 >= (int)p.bin_lo && 4 * kq < (int)p.bin_hi)
             reinterpret_cast<uint2*>(slot)[rgba_flush::slot_cell<kRF>(kq, fg) * 2 + (wave & 1)] = make_uint2(shifted ? wb : wa, wb);
         }
         wave_sync();  // the buffer is rewritten by the next half / the next iteration's transpose
@@ -633,12 +634,12 @@ bool fast2048_available(const StftParams& p) {
   return !(p.out_bins & 3) && !(p.out_bin0 & 3) && !(reinterpret_cast<uintptr_t>(p.out) & 3);
 }
 
-// The image output needs whole 16-bin groups, the flipped full-height row mapping, a colour table and the scratch
+// The image output needs the flipped full-height row mapping, a colour table and the scratch
 // buffer (fast_rgba_scratch_bytes()).
 bool fast2048_rgba_available(const StftParams& p) {
   if (p.n != 2048 || p.nframes < 2) return false;
   if (!((p.fast_mode == 1 && p.fast_table) || (p.fast_mode == 2 && p.twiddles))) return false;
-  if ((p.bin_lo & 15) || (p.bin_hi & 15) || p.bin_lo >= p.bin_hi) return false;
+  if (p.bin_lo >= p.bin_hi) return false;
   if (p.row_of_bin0 != (int32_t)p.bin_hi - 1) return false;
   return p.width != 0 && p.width <= ((uint64_t)1 << 24) && p.lut;
 }
@@ -651,10 +652,7 @@ int launch_stft_fast2048(const StftParams& p, void* stream_v) {
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_v);
   FastScale fs = make_fast_scale(p.scale_mode, p.n, p.gain_db, p.range_db);
   fs.b -= 2.0f * fs.a;  // the pair separation leaves 2*X: |2X|^2 = 4|X|^2
-  int dev = 0, cus = 256;
-  hipDeviceProp_t prop;
-  if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
-    cus = prop.multiProcessorCount;
+  const int cus = device_cu_count();
   const uint64_t nunits = (p.nframes + 1) / 2;
   const uint64_t need = (nunits + kWaves - 1) / kWaves;
   const uint32_t grid = (uint32_t)(need < (uint64_t)cus ? need : (uint64_t)cus);  // persistent: one workgroup per CU
@@ -672,9 +670,7 @@ int launch_stft_fast2048(const StftParams& p, void* stream_v) {
 #define SONO_R2048_T(PL, In, H, T)                                                                              \
   do {                                                                                                          \
     auto kern = stft2048_rgba_kernel<PL, In, H, T>;                                                             \
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,    \
-                            kLdsBytes) != hipSuccess)                                                           \
-      return SONO_ERR_DEVICE;                                                                                   \
+    SONO_GRANT_LDS(kern, kLdsBytes);                                                                            \
     hipLaunchKernelGGL(kern, dim3(rgrid), dim3(kWaves * 64), kLdsBytes, stream, p, fs, table, tiles);           \
   } while (0)
 #define SONO_R2048_H(PL, In)                                                \
@@ -686,6 +682,7 @@ int launch_stft_fast2048(const StftParams& p, void* stream_v) {
 #undef SONO_R2048_H
 #undef SONO_R2048_T
 #undef SONO_R2048
+    note_kernel(tab ? "stft2048_rgba_kernel<table>" : "stft2048_rgba_kernel<roots>");
     return hipGetLastError() == hipSuccess ? SONO_OK : SONO_ERR_DEVICE;
   }
 #define SONO_L2048(PL, In, FE, H)                                                                               \
@@ -695,9 +692,7 @@ int launch_stft_fast2048(const StftParams& p, void* stream_v) {
 #define SONO_L2048_T(PL, In, FE, H, T)                                                                          \
   do {                                                                                                          \
     auto kern = stft2048_kernel<PL, In, FE, H, T>;                                                               \
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,    \
-                            kLdsBytes) != hipSuccess)                                                           \
-      return SONO_ERR_DEVICE;                                                                                   \
+    SONO_GRANT_LDS(kern, kLdsBytes);                                                                            \
     hipLaunchKernelGGL(kern, dim3(grid), dim3(kWaves * 64), kLdsBytes, stream, p, fs, table);                   \
   } while (0)
 #define SONO_L2048_F(PL, In)                                                                                   \
@@ -710,6 +705,7 @@ int launch_stft_fast2048(const StftParams& p, void* stream_v) {
 #undef SONO_L2048_F
 #undef SONO_L2048_T
 #undef SONO_L2048
+  note_kernel(tab ? "stft2048_kernel<table>" : "stft2048_kernel<roots>");
   return hipGetLastError() == hipSuccess ? SONO_OK : SONO_ERR_DEVICE;
 }
 

@@ -21,6 +21,7 @@
 
 #include "sono_device.h"
 #include "sono_internal.h"
+#include "sono_launch.h"
 #include "sono_rgba_flush.h"
 
 namespace sono {
@@ -531,7 +532,7 @@ __global__ __launch_bounds__(kWaves * 64) void stft512_rgba_kernel(StftParams p,
           w4[2] = c3;
         }
         const int kq = 32 * P + le;
-        if (4 * kq >= (int)p.bin_lo && 4 * kq < (int)p.bin_hi)
+        if (4 * kq + 3 >= (int)p.bin_lo && 4 * kq < (int)p.bin_hi)
           reinterpret_cast<uint4*>(slot)[rgba_flush::slot_cell<kRF>(kq, fg)] = make_uint4(w4[0], w4[1], w4[2], w4[3]);
         wave_sync();  // the buffer is rewritten by the next half / the next iteration's transpose
       }
@@ -571,12 +572,12 @@ bool fast512_available(const StftParams& p) {
   return !(p.out_bins & 3) && !(p.out_bin0 & 3) && !(reinterpret_cast<uintptr_t>(p.out) & 3);
 }
 
-// The image output needs whole 16-bin groups, the flipped full-height row mapping, a LUT and the scratch buffer
+// The image output needs the flipped full-height row mapping, a LUT and the scratch buffer
 // (fast_rgba_scratch_bytes()).
 bool fast512_rgba_available(const StftParams& p) {
   if (p.n != 512 || p.nframes < 8) return false;
   if (!((p.fast_mode == 1 && p.fast_table) || (p.fast_mode == 2 && p.twiddles))) return false;
-  if ((p.bin_lo & 15) || (p.bin_hi & 15) || p.bin_lo >= p.bin_hi) return false;
+  if (p.bin_lo >= p.bin_hi) return false;
   if (p.row_of_bin0 != (int32_t)p.bin_hi - 1) return false;
   return p.width != 0 && p.width <= ((uint64_t)1 << 24) && p.lut;
 }
@@ -589,10 +590,7 @@ int launch_stft_fast512(const StftParams& p, void* stream_v) {
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_v);
   FastScale fs = make_fast_scale(p.scale_mode, p.n, p.gain_db, p.range_db);
   fs.b -= 2.0f * fs.a;  // the pair separation leaves 2*X: |2X|^2 = 4|X|^2
-  int dev = 0, cus = 256;
-  hipDeviceProp_t prop;
-  if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
-    cus = prop.multiProcessorCount;
+  const int cus = device_cu_count();
   const uint64_t nunits = (p.nframes + 7) / 8;
   const uint64_t need = (nunits + kWaves - 1) / kWaves;
   const uint32_t grid = (uint32_t)(need < (uint64_t)cus ? need : (uint64_t)cus);  // persistent: one workgroup per CU
@@ -607,9 +605,7 @@ int launch_stft_fast512(const StftParams& p, void* stream_v) {
 #define SONO_R512(PL, In, H, T)                                                                                 \
   do {                                                                                                          \
     auto kern = stft512_rgba_kernel<PL, In, H, T>;                                                              \
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,    \
-                            lds) != hipSuccess)                                                                 \
-      return SONO_ERR_DEVICE;                                                                                   \
+    SONO_GRANT_LDS(kern, lds);                                                                                  \
     hipLaunchKernelGGL(kern, dim3(rgrid), dim3(kWaves * 64), lds, stream, p, fs, table, tiles);                 \
   } while (0)
 #define SONO_R512_H(PL, In)                                                                                    \
@@ -621,14 +617,13 @@ int launch_stft_fast512(const StftParams& p, void* stream_v) {
     else { if (i16) SONO_R512_H(false, int16_t); else SONO_R512_H(false, float); }
 #undef SONO_R512_H
 #undef SONO_R512
+    note_kernel(tab ? "stft512_rgba_kernel<table>" : "stft512_rgba_kernel<roots>");
     return hipGetLastError() == hipSuccess ? SONO_OK : SONO_ERR_DEVICE;
   }
 #define SONO_L512(PL, In, FE, H, T)                                                                              \
   do {                                                                                                          \
     auto kern = stft512_kernel<PL, In, FE, H, T>;                                                                \
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,    \
-                            kLdsBytes) != hipSuccess)                                                           \
-      return SONO_ERR_DEVICE;                                                                                   \
+    SONO_GRANT_LDS(kern, kLdsBytes);                                                                            \
     hipLaunchKernelGGL(kern, dim3(grid), dim3(kWaves * 64), kLdsBytes, stream, p, fs, table);                   \
   } while (0)
 #define SONO_L512_F(PL, In)                                                                                   \
@@ -645,6 +640,7 @@ int launch_stft_fast512(const StftParams& p, void* stream_v) {
   else { if (i16) SONO_L512_F(false, int16_t); else SONO_L512_F(false, float); }
 #undef SONO_L512_F
 #undef SONO_L512
+  note_kernel(tab ? "stft512_kernel<table>" : "stft512_kernel<roots>");
   return hipGetLastError() == hipSuccess ? SONO_OK : SONO_ERR_DEVICE;
 }
 

@@ -20,6 +20,7 @@
 
 #include "sono_device.h"
 #include "sono_internal.h"
+#include "sono_launch.h"
 
 namespace sono {
 
@@ -287,9 +288,7 @@ int launch_stft_general(const StftParams& p, bool exact_f64, void* stream_v) {
   dim3 grid((uint32_t)blocks), block(kThreads);
 #define SONO_LAUNCH(A, In)                                                                                  \
   do {                                                                                                      \
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&stft_general_kernel<A, In>),                     \
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)            \
-      return SONO_ERR_DEVICE;                                                                               \
+    SONO_GRANT_LDS((&stft_general_kernel<A, In>), lds);                                                     \
     hipLaunchKernelGGL((stft_general_kernel<A, In>), grid, block, lds, stream, p, fs, ft, stride);          \
   } while (0)
   if (exact_f64) {
@@ -298,6 +297,7 @@ int launch_stft_general(const StftParams& p, bool exact_f64, void* stream_v) {
     if (p.in_kind == SONO_IN_I16) SONO_LAUNCH(float, int16_t); else SONO_LAUNCH(float, float);
   }
 #undef SONO_LAUNCH
+  note_kernel(exact_f64 ? "stft_general_kernel<double>" : "stft_general_kernel<float>");
   return hipGetLastError() == hipSuccess ? SONO_OK : SONO_ERR_DEVICE;
 }
 

@@ -25,6 +25,7 @@
 
 #include "sono_device.h"
 #include "sono_internal.h"
+#include "sono_launch.h"
 
 namespace sono {
 namespace mw {
@@ -326,10 +327,7 @@ int launch_stft_mw(const StftParams& p, void* stream_v) {
   fs.b -= 2.0f * fs.a;  // the pair separation leaves 2*X
   fs.db_off -= 2.0f * 3.0102999566f;
   const uint64_t npairs = (p.nframes + 1) / 2;
-  int dev = 0, cus = 256;
-  hipDeviceProp_t prop;
-  if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
-    cus = prop.multiProcessorCount;
+  const int cus = device_cu_count();
   const int groups = p.n == 512 ? 8 : 1;  // transforms per workgroup
   const uint64_t need = (npairs + groups - 1) / groups;
   const uint64_t cap = (uint64_t)cus * (p.n == 2048 ? 8 : 4);
@@ -362,6 +360,7 @@ int launch_stft_mw(const StftParams& p, void* stream_v) {
 #undef SONO_MW_IN
 #undef SONO_MW_M
 #undef SONO_MW
+  note_kernel(p.n == 4096 ? "stft_mw_kernel<4096>" : p.n == 2048 ? "stft_mw_kernel<2048>" : "stft_mw_kernel<512>");
   return hipGetLastError() == hipSuccess ? SONO_OK : SONO_ERR_DEVICE;
 }
 

@@ -49,6 +49,9 @@ struct StftParams {
   double gain_db, range_db;
 };
 
+// Every launch_* function reports the kernel it enqueued (a static string), for sono_kernel_route.
+void note_kernel(const char* name);
+
 // kernels_general.hip: table-driven radix-2 dataflow, any power-of-two size, both arithmetics.
 int launch_stft_general(const StftParams& p, bool exact_f64, void* hip_stream);
 // kernels_fast.hip: float32 kernels with accurate twiddles (returns 1 if this size/mode has no fast kernel).

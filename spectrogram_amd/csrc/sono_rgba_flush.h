@@ -52,8 +52,9 @@ __device__ __forceinline__ void flush_quarter_store(const StftParams& p, const u
   const int64_t width4 = (int64_t)p.width * 4;
   const uint32_t voff = (uint32_t)(4 - 4 * qsel) * (uint32_t)width4 + 16u * fsel;
   const bool whole = frame0 + RF <= p.nframes;  // workgroup-uniform
-  const int bin0 = 32 * wave + 8 * part;                  // wave-uniform; the band is made of 16-bin groups
-  if (bin0 < (int)p.bin_lo || bin0 >= (int)p.bin_hi) return;
+  const int bin0 = 32 * wave + 8 * part;                  // wave-uniform
+  if (bin0 + 8 <= (int)p.bin_lo || bin0 >= (int)p.bin_hi) return;
+  const int binq = bin0 + 4 * qsel;                       // this lane's rows are the bins binq .. binq + 3
 #pragma unroll
   for (int u = 0; u < RF / 128; ++u) {
     const uint64_t fl = frame0 + 128 * u + 4 * fsel;  // this lane's first frame
@@ -69,6 +70,7 @@ __device__ __forceinline__ void flush_quarter_store(const StftParams& p, const u
       px.z = lut_lds[(q[u].z >> (8 * i)) & 255u];
       px.w = lut_lds[(q[u].w >> (8 * i)) & 255u];
       uint8_t* dst = base - (int64_t)i * width4 + voff;
+      if (binq + i < (int)p.bin_lo || binq + i >= (int)p.bin_hi) continue;  // a band may start or end inside a quad
       if (whole) {
         *reinterpret_cast<u32x4_unaligned*>(dst) = px;
       } else {  // the last round of the recording

@@ -135,6 +135,14 @@ class Engine:
     def wait(self):
         self._check(self._lib.sono_wait(self._ctx))
 
+    def kernel_route(self):
+        """Kernels the most recent transform call enqueued (sono_kernel_route)."""
+        return self._lib.sono_kernel_route(self._ctx).decode()
+
+    def reserve(self, n_samples):
+        """Size the staging buffers for host calls of up to n_samples (sono_reserve)."""
+        self._check(self._lib.sono_reserve(self._ctx, int(n_samples)))
+
     # -- device memory owned by the caller
     def device_malloc(self, nbytes):
         p = self._lib.sono_device_malloc(self._ctx, int(nbytes))

@@ -325,6 +325,44 @@ def test_full_size_periodic_property():
     assert d.max() <= 1
 
 
+def test_kernel_route_is_visible_and_default_view_is_fast():
+    """sono_kernel_route names the kernels of the last call, so a fall-back to the general kernel shows.  The
+    viewer's default view (wsManager.js:29-47: 10-128 kHz; at 384 kHz and FFT 1024 that is bins 26..340, neither
+    end on a four-bin group) must be written by the fused 1024-point image kernel, within 1 LSB of the checker."""
+    sy, sh = E.plugin_crop(512, 384000, 10000, 128000)
+    lo, hi = 512 - sy - sh, 512 - sy
+    assert (lo, hi) == (26, 341)
+    x = G.signal("bat")
+    ref = oracle.plugin_get_frequencies(x, 1024, 768)
+    lut = (np.arange(1024, dtype=np.uint32) * 7 % 256).astype(np.uint8)
+    with plugin_engine(1024, 256, F.ARITH_FAST_F32, out_kind=F.OUT_RGBA8, bin_lo=lo, bin_hi=hi) as eng:
+        assert eng.kernel_route() == ""
+        eng.set_colormap(lut)
+        img = eng.stft(x)
+        assert eng.kernel_route() == "stft1024_u8_kernel<table>:rgba"
+    want = ref[:, lo:hi].T[::-1].astype(np.int16)
+    l4 = lut.reshape(256, 4)
+    ok = np.zeros(want.shape, bool)
+    for dlt in (-1, 0, 1):
+        ok |= np.all(img == l4[(want + dlt) % 256], axis=-1)           # <= 1 LSB, cyclic at the 256 -> 0 wrap
+    assert img.shape == want.shape + (4,) and ok.all()
+    assert np.all(img == l4[want], axis=-1).mean() > 0.98
+    # routes of other contexts: worker render, 4096 points (index kernel + colour-map kernel), a size with no
+    # specialised kernel, exact arithmetic
+    with worker_engine(1024, 256, F.ARITH_FAST_F32) as eng:
+        eng.stft(x)
+        assert eng.kernel_route() == "stft1024_u8_kernel<roots>:rgba + stft_general_kernel<float>"   # + the wrapped last frame
+    with plugin_engine(4096, 256, F.ARITH_FAST_F32, out_kind=F.OUT_RGBA8, bin_lo=160, bin_hi=1280) as eng:
+        eng.stft(x)
+        assert eng.kernel_route() == "stft_mw_kernel<4096>:u8 + colorize_kernel"
+    with plugin_engine(256, 64, F.ARITH_FAST_F32) as eng:
+        eng.stft(x)
+        assert eng.kernel_route() == "stft_general_kernel<float>"
+    with plugin_engine(1024, 256, F.ARITH_EXACT_F64) as eng:
+        eng.stft(x)
+        assert eng.kernel_route() == "stft1024_exact_kernel"
+
+
 # ------------------------------------------------------------------ per-frame features (SONO_OUT_FEATURES)
 def test_features_exact_bit_exact_against_checker():
     """Integer feature indices are bit-exact: peak_bin is the strict-> first-wins argmax of the float32
