@@ -272,6 +272,18 @@ const char* sono_kernel_route(const sono_ctx* ctx);
  * No counterpart in the reference. */
 int sono_reserve(sono_ctx* ctx, uint64_t n_samples);
 
+/* sono_stft_async for callers that cannot allocate device memory or let a library do so (code under HIP graph
+ * capture, tight serving loops, harnesses that forbid hipMalloc); it has no counterpart in the reference.
+ * SONO_OUT_RGBA8 contexts only.  The call's colour indices ([frame][bin] uint8, the band rounded outwards to
+ * groups of four bins) go through a device array of SONO_STATIC_SCRATCH_BYTES that is part of the library's code
+ * object: every GPU the library runs on holds one copy until the process ends.  A call whose frames x bins exceed
+ * that size returns SONO_ERR_CAPACITY (32 MiB = 65 536 frames of 512 bins, i.e. 43 s at 384 kHz, FFT 1024,
+ * hop 256; the reference loads files of at most 20 s, fileLoader.js:181).  Calls on the same GPU share the
+ * array, whichever context or stream they use: two such calls must not overlap in time.  Same result as
+ * sono_stft_async, enqueued on the context's stream without waiting, no hipMalloc / hipFree inside. */
+#define SONO_STATIC_SCRATCH_BYTES (32u << 20)
+int sono_stft_static(sono_ctx* ctx, const void* pcm_dev, uint64_t n_samples, void* out_dev, uint64_t out_capacity_bytes);
+
 /* Host pointers, enqueued without waiting: copy in, transform, copy out on the context's stream, through
  * the context's staging buffers (so: one transform in flight per context; a batch host cycles over a
  * few contexts to overlap the copies of one file with the transform of another).  The copies only run

@@ -27,6 +27,7 @@ ARITH_FAST_F32, ARITH_EXACT_F64 = 0, 1
 OUT_U8_INDEX, OUT_RGBA8, OUT_F32_DB, OUT_F32_MAG, OUT_FEATURES = 0, 1, 2, 3, 4
 IN_F32, IN_I16 = 0, 1
 MEM_HOST, MEM_DEVICE = 0, 1
+STATIC_SCRATCH_BYTES = 32 << 20
 FREQ_SCALES = {"linear": 0, "mel": 1, "logarithmic": 2, "bark": 3, "erb": 4}
 
 
@@ -109,6 +110,7 @@ SYMBOLS = {
     "sono_stft": (C.c_int, [_VP, _VP, C.c_uint64, _VP, C.c_uint64, C.c_int]),
     "sono_stft_async": (C.c_int, [_VP, _VP, C.c_uint64, _VP, C.c_uint64]),
     "sono_wait": (C.c_int, [_VP]),
+    "sono_stft_static": (C.c_int, [_VP, _VP, C.c_uint64, _VP, C.c_uint64]),
     "sono_kernel_route": (C.c_char_p, [_VP]),
     "sono_reserve": (C.c_int, [_VP, C.c_uint64]),
     "sono_resample": (C.c_int, [_VP, _VP, C.c_uint64, C.c_uint32, C.c_uint64, _VP, C.c_int]),

@@ -49,6 +49,28 @@ struct sono_ctx {
   std::string err;
 };
 
+// The index plane of sono_stft_static: one array per GPU, part of the code object, so that the entry point
+// needs no allocation.  Host code never uses the array's name as an address; the per-device address comes from
+// hipGetSymbolAddress (static_scratch_of).
+static __device__ __align__(256) unsigned char scratch[SONO_STATIC_SCRATCH_BYTES];
+static void* g_scratch_ptr[64];       // per device, resolved with that device current
+static bool g_scratch_tried[64];
+
+// Device address of `scratch` on the current device `dev`, or nullptr.  Called from sono_create.
+static void* static_scratch_of(int dev) {
+  if (dev < 0 || dev >= 64) return nullptr;
+  if (!g_scratch_tried[dev]) {
+    void* ptr = nullptr;
+    if (hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch)) != hipSuccess) {
+      (void)hipGetLastError();
+      ptr = nullptr;
+    }
+    g_scratch_ptr[dev] = ptr;
+    g_scratch_tried[dev] = true;
+  }
+  return g_scratch_ptr[dev];
+}
+
 static thread_local const char* t_kernel = "";
 namespace sono {
 void note_kernel(const char* name) { t_kernel = name; }
@@ -220,6 +242,7 @@ sono_ctx* sono_create(int device, const sono_config* cfg) {
     if ((e = hipMemcpy(c->d_fast, t.data(), sizeof(float) * t.size(), hipMemcpyHostToDevice)) != hipSuccess)
       return bail("hipMemcpy(fast table)", e);
   }
+  (void)static_scratch_of(device);  // the device is current: resolve this GPU's copy of the static index plane
   if (refresh_routes(c) != SONO_OK) {
     g_create_error = c->err;
     sono_destroy(c);
@@ -564,6 +587,15 @@ int sono_stft_async(sono_ctx* c, const void* pcm, uint64_t L, void* out, uint64_
   if (!c) return SONO_ERR_ARG;
   const IndexScratch aux = {c->d_aux, c->d_aux_bytes, false};
   return transform(c, pcm, L, out, cap, aux, true);
+}
+
+int sono_stft_static(sono_ctx* c, const void* pcm, uint64_t L, void* out, uint64_t cap) {
+  if (!c) return SONO_ERR_ARG;
+  if (c->cfg.out_kind != SONO_OUT_RGBA8) return fail(c, SONO_ERR_ARG, "sono_stft_static serves SONO_OUT_RGBA8 contexts");
+  void* sp = (c->device >= 0 && c->device < 64) ? g_scratch_ptr[c->device] : nullptr;
+  if (!sp) return fail(c, SONO_ERR_DEVICE, "the static index plane has no address on device %d", c->device);
+  const IndexScratch aux = {sp, (uint64_t)SONO_STATIC_SCRATCH_BYTES, true};
+  return transform(c, pcm, L, out, cap, aux, false);
 }
 
 const char* sono_kernel_route(const sono_ctx* c) { return c ? c->route.c_str() : ""; }

@@ -135,6 +135,14 @@ class Engine:
     def wait(self):
         self._check(self._lib.sono_wait(self._ctx))
 
+    def stft_static_device(self, pcm_ptr, n_samples, out_ptr, out_capacity, wait=True):
+        """sono_stft_static: the RGBA transform through the library's static index plane (no allocation)."""
+        rc = self._lib.sono_stft_static(self._ctx, C.c_void_p(pcm_ptr), int(n_samples), C.c_void_p(out_ptr),
+                                        int(out_capacity))
+        self._check(rc)
+        if wait:
+            self.wait()
+
     def kernel_route(self):
         """Kernels the most recent transform call enqueued (sono_kernel_route)."""
         return self._lib.sono_kernel_route(self._ctx).decode()
