@@ -59,9 +59,13 @@ def split_recording(n_samples, fft_n, hop, world_size, frame_rule=F.FRAMES_PLUGI
     return spans
 
 
-def merge_calls(call_lists):
+def merge_calls(call_lists, min_frames=1):
     """Concatenate per-span call records (absolute frame numbers, spans in order) and stitch a run that
-    ends on the last frame of one span to a run that starts on the first frame of the next."""
+    ends on the last frame of one span to a run that starts on the first frame of the next.
+
+    Segment every span with min_frames=1 and give the minimum run length HERE: it applies to the stitched
+    runs, so a call that crosses a span boundary as two short pieces is kept or dropped as the whole-recording
+    pass would keep or drop it (a per-span minimum would drop the pieces before they meet)."""
     import numpy as np
     merged = []
     for calls in call_lists:
@@ -77,6 +81,7 @@ def merge_calls(call_lists):
                     p["peak_idx"], p["peak_bin"], p["peak_frame"] = c["peak_idx"], c["peak_bin"], c["peak_frame"]
             else:
                 merged.append(c)
+    merged = [c for c in merged if int(c["end_frame"]) - int(c["start_frame"]) + 1 >= int(min_frames)]
     out = np.zeros(len(merged), F.CALL_DTYPE)
     for i, c in enumerate(merged):
         out[i] = c
@@ -116,6 +121,8 @@ class FilePipeline:
         self._out_bytes = int(e0.out_bytes(int(max_samples)))
         self.max_samples = int(max_samples)
         self._pin_in, self._pin_out, self._busy = [], [], [None] * slots
+        for e in self.engines:
+            e.reserve(self.max_samples)      # staging sized now: no allocation (= device-wide wait) between files
         for _ in range(slots):
             pi, po = self._lib.sono_host_malloc(max(4, self._in_bytes)), self._lib.sono_host_malloc(max(4, self._out_bytes))
             if not pi or not po:

@@ -72,6 +72,24 @@ def test_merge_calls_stitches_across_spans():
     assert merged.tobytes() == whole.tobytes()
 
 
+def test_merge_calls_applies_min_frames_after_stitching():
+    """A 4-frame run crossing the boundary at frame 32 as 2 + 2 survives min_frames=3 (as in the whole-recording
+    pass); a 2-frame run inside a span and a 1 + 1 run across the boundary do not."""
+    f = np.zeros(96, F.FEATURE_DTYPE)
+    f["peak_bin"] = 200 - np.arange(96)
+    f["peak_idx"][30:34] = 190          # 2 + 2 across frame 32
+    f["peak_idx"][10:12] = 190          # short run inside span 0
+    f["peak_idx"][63:65] = 190          # 1 + 1 across frame 64
+    f["peak_idx"][70:80] = 210
+    whole = E.segment_calls(f, 100, 3)
+    assert [(int(c["start_frame"]), int(c["end_frame"])) for c in whole] == [(30, 33), (70, 79)]
+    parts = [E.segment_calls(f[a:b], 100, 1, first_frame=a) for a, b in ((0, 32), (32, 64), (64, 96))]
+    assert sharding.merge_calls(parts, min_frames=3).tobytes() == whole.tobytes()
+    # the per-span minimum loses the boundary call
+    lossy = [E.segment_calls(f[a:b], 100, 3, first_frame=a) for a, b in ((0, 32), (32, 64), (64, 96))]
+    assert len(sharding.merge_calls(lossy)) == 1
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
