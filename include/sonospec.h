@@ -267,6 +267,12 @@ int sono_wait(sono_ctx* ctx);
  * hosts print this so that the fall-back is visible.  No counterpart in the reference. */
 const char* sono_kernel_route(const sono_ctx* ctx);
 
+/* SONO_OUT_FEATURES in the float32 arithmetic: number of records of the most recent launch that the float32 kernel
+ * could not decide (two top bins too close, or the peak too close to a step of the quantiser) and that were
+ * recomputed in the exact arithmetic, which is why feature records are the reference's in both arithmetics.  Waits
+ * for the context's stream.  0 for other contexts.  No counterpart in the reference. */
+int64_t sono_features_recomputed(sono_ctx* ctx);
+
 /* Sizes the context's staging buffers for recordings of up to n_samples, so that later sono_stft_host_async calls
  * of that size or less do not allocate (an allocation waits for the whole device).  May allocate and wait itself.
  * No counterpart in the reference. */

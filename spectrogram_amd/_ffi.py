@@ -112,6 +112,7 @@ SYMBOLS = {
     "sono_wait": (C.c_int, [_VP]),
     "sono_stft_static": (C.c_int, [_VP, _VP, C.c_uint64, _VP, C.c_uint64]),
     "sono_kernel_route": (C.c_char_p, [_VP]),
+    "sono_features_recomputed": (C.c_int64, [_VP]),
     "sono_reserve": (C.c_int, [_VP, C.c_uint64]),
     "sono_resample": (C.c_int, [_VP, _VP, C.c_uint64, C.c_uint32, C.c_uint64, _VP, C.c_int]),
     "sono_resample_cols": (C.c_int, [_VP, _VP, C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint64, C.c_uint64, _VP, C.c_int]),

@@ -25,6 +25,8 @@ struct sono_ctx {
   // device tables
   float* d_window = nullptr;
   void* d_tw = nullptr;       // float2[n-1] (fast) or double2[n-1] (exact)
+  void* d_tw_exact = nullptr; // double2[n-1] beside a float2 d_tw: the feature pass recomputes doubtful frames exactly
+  void* d_claim = nullptr;    // the queue of that recomputation (features_fixup_queue_bytes(kFixupCapacity))
   uint32_t* d_lut = nullptr;  // 256 packed pixels
   void* d_fast = nullptr;     // twiddle matrix of the fast kernel (accurate twiddles only)
   bool have_lut = false;
@@ -45,6 +47,7 @@ struct sono_ctx {
   uint32_t fast_mode = 0;   // StftParams::fast_mode
   bool mw_ok = false;       // StftParams::mw_ok
   bool pair_exact = false;  // StftParams::pair_exact
+  double pair_asym = 0;     // StftParams::pair_asym
   std::string route;        // kernels of the most recent transform call (sono_kernel_route)
   std::string err;
 };
@@ -75,6 +78,9 @@ static thread_local const char* t_kernel = "";
 namespace sono {
 void note_kernel(const char* name) { t_kernel = name; }
 }
+
+// Frames that the feature fix-up pass can list per launch (4 MiB; beyond it the pass scans for the rest).
+constexpr uint32_t kFixupCapacity = 1u << 20;
 
 static thread_local std::string g_create_error;
 
@@ -124,6 +130,14 @@ static int upload_tables(sono_ctx* c) {
     }
     HIP_TRY(c, hipMemcpyAsync(c->d_tw, t.data(), sizeof(float) * t.size(), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (c->d_tw_exact) {
+      std::vector<double> d(2 * (size_t)(n - 1));
+      for (uint32_t i = 0; i + 1 < n; i++) {
+        d[2 * i] = c->h_cos[i];
+        d[2 * i + 1] = c->h_sin[i];
+      }
+      HIP_TRY(c, hipMemcpy(c->d_tw_exact, d.data(), sizeof(double) * d.size(), hipMemcpyHostToDevice));
+    }
   }
   return SONO_OK;
 }
@@ -230,6 +244,11 @@ sono_ctx* sono_create(int device, const sono_config* cfg) {
     for (uint32_t i = 0; i < 256; ++i) grey[i] = i * 0x010101u | 0xFF000000u;
     if ((e = hipMemcpy(c->d_lut + 256, grey, 1024, hipMemcpyHostToDevice)) != hipSuccess) return bail("hipMemcpy(lut)", e);
   }
+  if (cfg->arith == SONO_ARITH_FAST_F32 && cfg->out_kind == SONO_OUT_FEATURES &&
+      (e = hipMalloc(&c->d_tw_exact, sizeof(double) * 2 * n)) != hipSuccess)
+    return bail("hipMalloc(exact twiddles)", e);
+  if (c->d_tw_exact && (e = hipMalloc(&c->d_claim, features_fixup_queue_bytes(kFixupCapacity))) != hipSuccess)
+    return bail("hipMalloc(fix-up queue)", e);
   if (upload_tables(c) != SONO_OK) {
     g_create_error = c->err;
     sono_destroy(c);
@@ -255,7 +274,7 @@ void sono_destroy(sono_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
-  void* bufs[] = {c->d_window, c->d_tw, c->d_lut, c->d_fast, c->d_in, c->d_out, c->d_aux, c->d_fb_bin, c->d_fb_w};
+  void* bufs[] = {c->d_window, c->d_tw, c->d_tw_exact, c->d_claim, c->d_lut, c->d_fast, c->d_in, c->d_out, c->d_aux, c->d_fb_bin, c->d_fb_w};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
   if (c->ev_start) (void)hipEventDestroy(c->ev_start);
@@ -387,7 +406,8 @@ constexpr uint64_t kMaxChunkBytes = (uint64_t)96 << 20;
 static int refresh_routes(sono_ctx* c) {
   c->fast_mode = compute_fast_mode(c);
   c->mw_ok = compute_mw_ok(c);
-  c->pair_exact = table_asymmetry(c) <= 5e-7;
+  c->pair_asym = table_asymmetry(c);
+  c->pair_exact = c->pair_asym <= 5e-7;
   if (c->cfg.out_kind == SONO_OUT_RGBA8) {
     const uint64_t want = c->fast_mode ? fast_rgba_scratch_bytes() : kDefaultChunkBytes;
     if (c->d_aux_bytes < want) {
@@ -492,9 +512,36 @@ static int launch_range(sono_ctx* c, const StftParams& q, const IndexScratch& au
   if (r == 1 && fast) r = launch_stft_fast2048(q, c->stream);
   if (r == 1 && q.mw_ok) r = launch_stft_mw(q, c->stream);
   if (exact) r = launch_stft_exact(q, c->stream);
+  // Feature records are integers that segmentation and species rules branch on, so they are the reference's in
+  // both arithmetics: a float32 kernel marks the frames it cannot decide (two top bins too close, peak too close
+  // to a step of the quantiser) and those records are recomputed in the exact arithmetic right behind it; where no
+  // float32 kernel with that marking serves, the pass runs in the exact arithmetic outright.
+  const bool feat_fast = q.out_kind == SONO_OUT_FEATURES && !exact && c->d_tw_exact && !q.fb_bin;
+  if (r == 1 && feat_fast) {
+    StftParams u = q;
+    u.twiddles = c->d_tw_exact;
+    r = launch_stft_general(u, true, c->stream);
+    if (r != SONO_OK) return fail(c, r, "kernel launch failed: %s", hipGetErrorString(hipGetLastError()));
+    note_route(c);
+    return SONO_OK;
+  }
   if (r == 1) r = launch_stft_general(q, exact, c->stream);
   if (r != SONO_OK) return fail(c, r, "kernel launch failed: %s", hipGetErrorString(hipGetLastError()));
   note_route(c);
+  if (feat_fast) {
+    StftParams u = q;
+    u.twiddles = c->d_tw_exact;
+    u.tile_scratch = c->d_claim;
+    u.fixup = kFixupCapacity;
+    r = launch_features_fixup(u, c->stream);
+    if (r == 1) {
+      u.fixup = 1;
+      HIP_TRY(c, hipMemsetAsync(c->d_claim, 0, 16, c->stream));
+      r = launch_stft_general(u, true, c->stream);
+    }
+    if (r != SONO_OK) return fail(c, r, "feature fix-up launch failed: %s", hipGetErrorString(hipGetLastError()));
+    note_route(c);
+  }
   return SONO_OK;
 }
 
@@ -531,6 +578,7 @@ static int transform(sono_ctx* c, const void* pcm, uint64_t L, void* out, uint64
   p.fast_mode = c->fast_mode;
   p.mw_ok = c->mw_ok ? 1u : 0u;
   p.pair_exact = c->pair_exact ? 1u : 0u;
+  p.pair_asym = c->pair_asym;
   p.fb_bin = c->d_fb_bin;
   p.fb_w0 = c->d_fb_w;
   p.fb_w1 = c->d_fb_w ? c->d_fb_w + n / 2 : nullptr;
@@ -599,6 +647,16 @@ int sono_stft_static(sono_ctx* c, const void* pcm, uint64_t L, void* out, uint64
 }
 
 const char* sono_kernel_route(const sono_ctx* c) { return c ? c->route.c_str() : ""; }
+
+int64_t sono_features_recomputed(sono_ctx* c) {
+  if (!c) return SONO_ERR_ARG;
+  if (!c->d_claim) return 0;
+  uint32_t words[2] = {0, 0};   // [0]: marked records of the 1024-point pass; [1]: of the general pass
+  HIP_TRY(c, hipSetDevice(c->device));
+  HIP_TRY(c, hipMemcpyAsync(words, c->d_claim, 8, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return (int64_t)words[0] + (int64_t)words[1];
+}
 
 int sono_reserve(sono_ctx* c, uint64_t L) {
   if (!c) return SONO_ERR_ARG;

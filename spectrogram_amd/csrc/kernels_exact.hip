@@ -64,7 +64,44 @@ __device__ __forceinline__ float ld<int16_t>(const int16_t* p, uint64_t i) {
   return (float)p[i] * (1.0f / 32768.0f);
 }
 
-template <typename In>
+// Queue of the fix-up pass (p.tile_scratch): a header of kQueueHeader words, then the list of marked frames.
+constexpr int kQueueCount = 0;    // number of marked records found (may exceed the list's capacity)
+constexpr int kQueueHeader = 4;
+constexpr int kCompactThreads = 256, kCompactPerThread = 16;
+
+// Lists the records that a float32 feature kernel marked (reserved[0] != 0): frame numbers within the launch, in
+// no particular order.  One workgroup per 4096 records collects its marks in LDS and reserves its piece of the
+// list with a single atomic (one atomic per marked record on one word would take longer than the scan).
+__global__ __launch_bounds__(kCompactThreads) void feature_marks_compact_kernel(const sono_frame_feature* __restrict__ marks,
+                                                                                uint64_t nframes, uint32_t* __restrict__ q,
+                                                                                uint32_t capacity) {
+  __shared__ uint32_t s_list[kCompactThreads * kCompactPerThread];
+  __shared__ uint32_t s_n, s_base;
+  if (threadIdx.x == 0) s_n = 0;
+  __syncthreads();
+  const uint64_t base = (uint64_t)blockIdx.x * (kCompactThreads * kCompactPerThread);
+  uint32_t word[kCompactPerThread];
+#pragma unroll
+  for (int j = 0; j < kCompactPerThread; ++j) {
+    const uint64_t f = base + (uint64_t)j * kCompactThreads + threadIdx.x;
+    word[j] = f < nframes ? reinterpret_cast<const uint32_t*>(marks + f)[1] : 0u;   // peak_idx, reserved[0..2]
+  }
+#pragma unroll
+  for (int j = 0; j < kCompactPerThread; ++j)
+    if (word[j] & 0xff00u) s_list[atomicAdd(&s_n, 1u)] = (uint32_t)(base + (uint64_t)j * kCompactThreads + threadIdx.x);
+  __syncthreads();
+  const uint32_t n = s_n;
+  if (n == 0) return;
+  if (threadIdx.x == 0) s_base = atomicAdd(q + kQueueCount, n);
+  __syncthreads();
+  const uint32_t at = s_base;
+  for (uint32_t i = threadIdx.x; i < n; i += kCompactThreads)
+    if (at + i < capacity) q[kQueueHeader + at + i] = s_list[i];
+}
+
+// FIXUP: `p.out` is a SONO_OUT_FEATURES output of a float32 kernel; only the records it marked (reserved[0] != 0)
+// are recomputed, each wavefront scanning blocks of 64 records and taking the marked frames two at a time.
+template <typename In, bool FIXUP>
 __global__ __launch_bounds__(kWaves * 64) void stft1024_exact_kernel(StftParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   double2* tw_lds = reinterpret_cast<double2*>(smem);                 // [31][32]: row t-1+j of stage T = 32t
@@ -86,9 +123,8 @@ __global__ __launch_bounds__(kWaves * 64) void stft1024_exact_kernel(StftParams 
   const double two_over_n = 2.0 / 1024.0;
   const bool worker = p.scale_mode == SONO_SCALE_WORKER_LOG5;
 
-  for (uint64_t base = (uint64_t)blockIdx.x * (kWaves * 2); base < p.nframes; base += (uint64_t)gridDim.x * (kWaves * 2)) {
-    const uint64_t fi = base + wave * 2 + h;      // frame of this half-wavefront within the launch
-    const bool live = fi < p.nframes;
+  // one frame per half-wavefront: frame `fi` of the launch; a spare half (live == false) stores nothing
+  auto process = [&](const uint64_t fi, const bool live) {
     const uint64_t frame = p.frame0 + (live ? fi : p.nframes - 1);  // a spare half repeats the last frame and stores nothing
     const uint64_t a = frame * p.hop;
 
@@ -143,7 +179,7 @@ __global__ __launch_bounds__(kWaves * 64) void stft1024_exact_kernel(StftParams 
     }
     wave_sync();
     const uint64_t orow = (p.col0 + fi) * p.out_bins;
-    if (p.out_kind == SONO_OUT_FEATURES) {
+    if (FIXUP || p.out_kind == SONO_OUT_FEATURES) {
       // first bin of the band whose float32 magnitude exceeds all earlier ones (strict >)
       float best_m = -1.0f, best_r = 0.0f, best_i = 0.0f;
       int best_k = (int)p.bin_lo;
@@ -197,6 +233,43 @@ __global__ __launch_bounds__(kWaves * 64) void stft1024_exact_kernel(StftParams 
       }
     }
     wave_sync();  // the buffer is rewritten by the next frame's transpose
+  };
+
+  if constexpr (FIXUP) {
+    // Marked records are rare, come in runs (the frames around the start of a call) and cost tens of microseconds each
+    // in this arithmetic; feature_marks_compact_kernel has listed them, and the wavefronts take the list two
+    // entries at a time, interleaved, so that a run of neighbouring frames is dealt out to as many wavefronts.
+    const uint32_t* q = reinterpret_cast<const uint32_t*>(p.tile_scratch);
+    const uint32_t listed = q[kQueueCount] < p.fixup ? q[kQueueCount] : p.fixup;   // p.fixup: capacity of the list
+    const uint32_t* list = q + kQueueHeader;
+    for (uint64_t e = ((uint64_t)blockIdx.x * kWaves + wave) * 2; e < listed; e += (uint64_t)gridDim.x * kWaves * 2) {
+      const bool two = e + 1 < listed;
+      process(list[e + ((h && two) ? 1 : 0)], h == 0 || two);
+    }
+    if (q[kQueueCount] > p.fixup) {
+      // more marked records than the list holds: the rest are found by scanning the records themselves (the
+      // listed ones are clean by now), one block of 64 records per wavefront at a time
+      const sono_frame_feature* marks = reinterpret_cast<const sono_frame_feature*>(p.out) + p.col0;
+      for (uint64_t blk = (uint64_t)blockIdx.x * kWaves + wave; blk * 64 < p.nframes; blk += (uint64_t)gridDim.x * kWaves) {
+        const uint64_t fl = blk * 64 + lane;
+        // (sc1: another workgroup of this launch may have cleaned the record; its stores are not in this CU's L1)
+        const uint32_t word = fl < p.nframes ? __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(marks + fl) + 1) : 0u;
+        uint64_t todo = __ballot((word & 0xff00u) != 0);
+        while (todo) {  // wave-uniform
+          const int i0 = __builtin_ctzll(todo);
+          todo &= todo - 1;
+          const bool two = todo != 0;
+          const int i1 = two ? __builtin_ctzll(todo) : i0;
+          if (two) todo &= todo - 1;
+          process(blk * 64 + (h ? i1 : i0), h == 0 || two);
+        }
+      }
+    }
+  } else {
+    for (uint64_t base = (uint64_t)blockIdx.x * (kWaves * 2); base < p.nframes; base += (uint64_t)gridDim.x * (kWaves * 2)) {
+      const uint64_t fi = base + wave * 2 + h;
+      process(fi, fi < p.nframes);
+    }
   }
 }
 
@@ -218,13 +291,46 @@ int launch_stft_exact(const StftParams& p, void* stream_v) {
   const uint32_t grid = (uint32_t)(need < (uint64_t)cus ? need : (uint64_t)cus);
 #define SONO_LAUNCH_X(In)                                                                                        \
   do {                                                                                                           \
-    auto kern = stft1024_exact_kernel<In>;                                                                       \
+    auto kern = stft1024_exact_kernel<In, false>;                                                                \
     SONO_GRANT_LDS(kern, kLdsBytes);                                                                             \
     hipLaunchKernelGGL(kern, dim3(grid), dim3(kWaves * 64), kLdsBytes, stream, p);                               \
   } while (0)
   if (p.in_kind == SONO_IN_I16) SONO_LAUNCH_X(int16_t); else SONO_LAUNCH_X(float);
 #undef SONO_LAUNCH_X
   note_kernel("stft1024_exact_kernel");
+  return hipGetLastError() == hipSuccess ? SONO_OK : SONO_ERR_DEVICE;
+}
+
+// p.tile_scratch: the queue (kQueueHeader words + p.fixup list entries, p.fixup >= 1).
+bool features_fixup_available(const StftParams& p) {
+  return p.n == 1024 && p.twiddles && !p.fb_bin && p.out_kind == SONO_OUT_FEATURES && p.nframes > 0 && p.tile_scratch &&
+         p.fixup > 0 && p.nframes < ((uint64_t)1 << 32);   // frame numbers are 32-bit list entries
+}
+
+uint64_t features_fixup_queue_bytes(uint32_t capacity) { return ((uint64_t)exact1024::kQueueHeader + capacity) * 4; }
+
+int launch_features_fixup(const StftParams& p, void* stream_v) {
+  using namespace exact1024;
+  if (!features_fixup_available(p)) return 1;
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_v);
+  if (hipMemsetAsync(p.tile_scratch, 0, kQueueHeader * 4, stream) != hipSuccess) return SONO_ERR_DEVICE;
+  const uint32_t per = kCompactThreads * kCompactPerThread;
+  hipLaunchKernelGGL(feature_marks_compact_kernel, dim3((uint32_t)((p.nframes + per - 1) / per)), dim3(kCompactThreads), 0, stream,
+                     reinterpret_cast<const sono_frame_feature*>(p.out) + p.col0, p.nframes, reinterpret_cast<uint32_t*>(p.tile_scratch),
+                     p.fixup);
+  // the list's length is only known on the device: a full grid, whose wavefronts find their entries or none
+  const uint64_t need = (p.nframes + kWaves * 2 - 1) / (kWaves * 2);
+  const uint64_t cap = (uint64_t)device_cu_count();   // 192 registers: one workgroup (two wavefronts per SIMD) per CU
+  const uint32_t grid = (uint32_t)(need < cap ? need : cap);
+#define SONO_LAUNCH_F(In)                                                                                        \
+  do {                                                                                                           \
+    auto kern = stft1024_exact_kernel<In, true>;                                                                 \
+    SONO_GRANT_LDS(kern, kLdsBytes);                                                                             \
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kWaves * 64), kLdsBytes, stream, p);                               \
+  } while (0)
+  if (p.in_kind == SONO_IN_I16) SONO_LAUNCH_F(int16_t); else SONO_LAUNCH_F(float);
+#undef SONO_LAUNCH_F
+  note_kernel("stft1024_exact_kernel<fixup>");
   return hipGetLastError() == hipSuccess ? SONO_OK : SONO_ERR_DEVICE;
 }
 

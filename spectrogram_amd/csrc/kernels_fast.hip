@@ -405,6 +405,7 @@ __global__ __launch_bounds__(kMaxWaves * 64, 4) void stft1024_u8_kernel(StftPara
     // FLT: the pair separation leaves 2*X; the plugin's magnitude is 2/N * |X| (spectrogram.esm.js:195-198)
     const float mag_scale = PLUGIN ? 1.0f / (float)kNPoints : 0.5f;
     float best_a = -1.0f, best_b = -1.0f;  // FEAT: this lane's largest |X|^2 so far and its bin
+    float next_a = -1.0f, next_b = -1.0f;  // FEAT: ... and the runner-up (what decides whether float32 can tell)
     int kbest_a = (int)p.bin_lo, kbest_b = (int)p.bin_lo;
     int lq = l;
     // (FEAT: an opaque copy keeps the loop-invariant bin numbers and band tests out of registers the transform needs;
@@ -439,9 +440,9 @@ __global__ __launch_bounds__(kMaxWaves * 64, 4) void stft1024_u8_kernel(StftPara
     const float br = (ZI) + (PI), bi = (PR) - (ZR);                          \
     const float ma = __builtin_fmaf(ar, ar, ai * ai);                        \
     const float mb = __builtin_fmaf(br, br, bi * bi);                        \
-    if constexpr (FEAT) { /* a lane visits its bins in ascending order */    \
-      if (in_band && ma > best_a) { best_a = ma; kbest_a = k + B; }          \
-      if (in_band && mb > best_b) { best_b = mb; kbest_b = k + B; }          \
+    if constexpr (FEAT) {                                                    \
+      fa[B] = ma;                                                            \
+      fb[B] = mb;                                                            \
     } else if constexpr (FLT) {                                              \
       fa[B] = OUT == kOutDb ? fast_db(ma, fs) : __builtin_sqrtf(ma) * mag_scale; \
       fb[B] = OUT == kOutDb ? fast_db(mb, fs) : __builtin_sqrtf(mb) * mag_scale; \
@@ -455,6 +456,18 @@ __global__ __launch_bounds__(kMaxWaves * 64, 4) void stft1024_u8_kernel(StftPara
         SONO_BIN(2, z23.x, z23.y, q23.x, q23.y)
         SONO_BIN(3, z23.z, z23.w, q23.z, q23.w)
 #undef SONO_BIN
+        if constexpr (FEAT) {
+          if (in_band) {  // (one branch per bin quad; selects inside)
+#pragma unroll
+            for (int B = 0; B < 4; ++B) {  // a lane visits its bins in ascending order
+              next_a = __builtin_amdgcn_fmed3f(fa[B], best_a, next_a);
+              next_b = __builtin_amdgcn_fmed3f(fb[B], best_b, next_b);
+              const bool ga = fa[B] > best_a, gb = fb[B] > best_b;
+              best_a = ga ? fa[B] : best_a; kbest_a = ga ? k + B : kbest_a;
+              best_b = gb ? fb[B] : best_b; kbest_b = gb ? k + B : kbest_b;
+            }
+          }
+        }
         if constexpr (RGBA) {
           wa2[g] = shifted ? wb : wa;  // an odd last frame was computed as B: it belongs in the A slot
           wb2[g] = wb;
@@ -484,25 +497,25 @@ __global__ __launch_bounds__(kMaxWaves * 64, 4) void stft1024_u8_kernel(StftPara
     }
     if constexpr (FEAT) {
       // reduce over the 32 lanes of the half-wavefront: larger |X|^2 wins, equal values go to the lower bin
-#pragma unroll
-      for (int m = 1; m < 32; m <<= 1) {
-        const float oa = __shfl_xor(best_a, m, 64), ob = __shfl_xor(best_b, m, 64);
-        const int ka = __shfl_xor(kbest_a, m, 64), kb = __shfl_xor(kbest_b, m, 64);
-        if (oa > best_a || (oa == best_a && ka < kbest_a)) { best_a = oa; kbest_a = ka; }
-        if (ob > best_b || (ob == best_b && kb < kbest_b)) { best_b = ob; kbest_b = kb; }
-      }
+      reduce_peak<32>(best_a, kbest_a, next_a);
+      reduce_peak<32>(best_b, kbest_b, next_b);
       if (l == 0) {
         sono_frame_feature* ft = reinterpret_cast<sono_frame_feature*>(p.out) + (p.col0 + f0);
+        // reserved[0] = 1: float32 cannot tell (two top bins too close, or the peak too close to a step of the
+        // quantiser); the exact-arithmetic pass that follows recomputes those records
+        const float ta = __builtin_fmaf(__log2f(best_a), fs.a, fs.b), tb = __builtin_fmaf(__log2f(best_b), fs.a, fs.b);
         if (st_a) {
           sono_frame_feature r{};
           r.peak_bin = kbest_a;
           r.peak_idx = (uint8_t)put_index<PLUGIN, 0>(best_a, fs, 0);
+          r.reserved[0] = feature_uncertain(best_a, next_a, best_b, ta, fs) ? 1 : 0;
           ft[0] = r;
         }
         if (st_b) {
           sono_frame_feature r{};
           r.peak_bin = kbest_b;
           r.peak_idx = (uint8_t)put_index<PLUGIN, 0>(best_b, fs, 0);
+          r.reserved[0] = feature_uncertain(best_b, next_b, best_a, tb, fs) ? 1 : 0;
           ft[1] = r;
         }
       }
@@ -597,6 +610,7 @@ int launch_stft_fast(const StftParams& p, void* stream_v) {
   // the pair separation leaves 2*X: |2X|^2 = 4|X|^2, i.e. log2 is 2 too large
   fs.b -= 2.0f * fs.a;
   fs.db_off -= 2.0f * 3.0102999566f;
+  fs.xtalk = (float)p.pair_asym;
   const uint64_t npairs = (p.nframes + 1) / 2;
   // one wavefront handles 2 pairs per iteration, or (RGBA) one 16-frame tile per 4 iterations
   const uint64_t per_wg = rgba ? (uint64_t)kRoundFrames / 2 : (uint64_t)kMaxWaves * 2;

@@ -385,6 +385,7 @@ __global__ __launch_bounds__(kWaves * 64) void stft2048_kernel(StftParams p, Fas
     asm volatile("" : "+v"(le));  // (keeps loop-invariant epilogue addresses out of registers the transforms need)
     const int kappa = (le & 31) + ((le >> 5) ? 0 : 32);
     float best_a = -1.0f, best_b = -1.0f;  // FEAT: largest |X|^2 so far and its bin
+    float next_a = -1.0f, next_b = -1.0f;  // FEAT: the runner-up (decides whether float32 can tell)
     int kbest_a = (int)p.bin_lo, kbest_b = (int)p.bin_lo;
     const uint64_t row_a = (p.col0 + fb) * p.out_bins, row_b = row_a + p.out_bins;
     const bool st_a = fb >= f0, st_b = true;  // fb + 1 < nframes always; frame fb belongs to this wavefront unless shifted
@@ -401,6 +402,7 @@ __global__ __launch_bounds__(kWaves * 64) void stft2048_kernel(StftParams p, Fas
         const float4 q01 = *reinterpret_cast<const float4*>(cell + kMirrorBase + j4);
         const float4 q23 = *reinterpret_cast<const float4*>(cell + kMirrorBase + j4 + 2);
         uint32_t wa = 0, wb = 0;
+        float pa[4] = {0, 0, 0, 0}, pb[4] = {0, 0, 0, 0};
         const bool in_band = k >= (int)p.bin_lo && k < (int)p.bin_hi;
 #define SONO_BIN(B, ZR, ZI, PR, PI)                                          \
   {                                                                          \
@@ -409,8 +411,8 @@ __global__ __launch_bounds__(kWaves * 64) void stft2048_kernel(StftParams p, Fas
     const float ma = __builtin_fmaf(ar, ar, ai * ai);                        \
     const float mb = __builtin_fmaf(br, br, bi * bi);                        \
     if constexpr (FEAT) { /* a lane visits its bins in ascending order */    \
-      if (in_band && ma > best_a) { best_a = ma; kbest_a = k + B; }          \
-      if (in_band && mb > best_b) { best_b = mb; kbest_b = k + B; }          \
+      pa[B] = ma;                                                            \
+      pb[B] = mb;                                                            \
     } else {                                                                 \
       wa = put_index<PLUGIN, B>(ma, fs, wa);                                 \
       wb = put_index<PLUGIN, B>(mb, fs, wb);                                 \
@@ -421,6 +423,18 @@ __global__ __launch_bounds__(kWaves * 64) void stft2048_kernel(StftParams p, Fas
         SONO_BIN(2, z23.x, z23.y, q23.x, q23.y)
         SONO_BIN(3, z23.z, z23.w, q23.z, q23.w)
 #undef SONO_BIN
+        if constexpr (FEAT) {
+          if (in_band) {  // (one branch per bin quad; selects inside)
+#pragma unroll
+            for (int B = 0; B < 4; ++B) {
+              next_a = __builtin_amdgcn_fmed3f(pa[B], best_a, next_a);
+              next_b = __builtin_amdgcn_fmed3f(pb[B], best_b, next_b);
+              const bool ga = pa[B] > best_a, gb = pb[B] > best_b;
+              best_a = ga ? pa[B] : best_a; kbest_a = ga ? k + B : kbest_a;
+              best_b = gb ? pb[B] : best_b; kbest_b = gb ? k + B : kbest_b;
+            }
+          }
+        }
         if (!FEAT && in_band) {
           const uint32_t col = k - p.out_bin0;
           if (st_a) *reinterpret_cast<uint32_t*>(out + row_a + col) = wa;
@@ -431,24 +445,23 @@ __global__ __launch_bounds__(kWaves * 64) void stft2048_kernel(StftParams p, Fas
     }
     if constexpr (FEAT) {
       // larger |X|^2 wins, equal values go to the lower bin
-#pragma unroll
-      for (int m = 1; m < 64; m <<= 1) {
-        const float oa = __shfl_xor(best_a, m, 64), ob = __shfl_xor(best_b, m, 64);
-        const int ka = __shfl_xor(kbest_a, m, 64), kb = __shfl_xor(kbest_b, m, 64);
-        if (oa > best_a || (oa == best_a && ka < kbest_a)) { best_a = oa; kbest_a = ka; }
-        if (ob > best_b || (ob == best_b && kb < kbest_b)) { best_b = ob; kbest_b = kb; }
-      }
+      reduce_peak<64>(best_a, kbest_a, next_a);
+      reduce_peak<64>(best_b, kbest_b, next_b);
       if (lane == 0) {
+        // reserved[0] = 1: float32 cannot tell; the exact-arithmetic pass that follows recomputes the record
         sono_frame_feature* ft = reinterpret_cast<sono_frame_feature*>(p.out) + (p.col0 + fb);
+        const float ta = __builtin_fmaf(__log2f(best_a), fs.a, fs.b), tb = __builtin_fmaf(__log2f(best_b), fs.a, fs.b);
         if (st_a) {
           sono_frame_feature r{};
           r.peak_bin = kbest_a;
           r.peak_idx = (uint8_t)put_index<PLUGIN, 0>(best_a, fs, 0);
+          r.reserved[0] = feature_uncertain(best_a, next_a, best_b, ta, fs) ? 1 : 0;
           ft[0] = r;
         }
         sono_frame_feature r{};
         r.peak_bin = kbest_b;
         r.peak_idx = (uint8_t)put_index<PLUGIN, 0>(best_b, fs, 0);
+        r.reserved[0] = feature_uncertain(best_b, next_b, best_a, tb, fs) ? 1 : 0;
         ft[1] = r;
       }
     }
@@ -652,6 +665,7 @@ int launch_stft_fast2048(const StftParams& p, void* stream_v) {
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_v);
   FastScale fs = make_fast_scale(p.scale_mode, p.n, p.gain_db, p.range_db);
   fs.b -= 2.0f * fs.a;  // the pair separation leaves 2*X: |2X|^2 = 4|X|^2
+  fs.xtalk = (float)p.pair_asym;
   const int cus = device_cu_count();
   const uint64_t nunits = (p.nframes + 1) / 2;
   const uint64_t need = (nunits + kWaves - 1) / kWaves;

@@ -304,6 +304,7 @@ __global__ __launch_bounds__(kWaves * 64) void stft512_kernel(StftParams p, Fast
     asm volatile("" : "+v"(le));
     float best[4] = {-1.0f, -1.0f, -1.0f, -1.0f};  // FEAT: largest |X|^2 so far of frame 2q + {0, 1}, q = transform read
     int kbest[4] = {(int)p.bin_lo, (int)p.bin_lo, (int)p.bin_lo, (int)p.bin_lo};
+    float next[4] = {-1.0f, -1.0f, -1.0f, -1.0f};  // FEAT: the runner-up (decides whether float32 can tell)
 #pragma unroll
     for (int P = 0; P < 2; ++P) {
       epilogue_cells(P, re, im, cell, le);
@@ -318,6 +319,7 @@ __global__ __launch_bounds__(kWaves * 64) void stft512_kernel(StftParams p, Fast
         const float4 q01 = *reinterpret_cast<const float4*>(mr);
         const float4 q23 = *reinterpret_cast<const float4*>(mr + 2);
         uint32_t wa = 0, wb = 0;
+        float pa[4] = {0, 0, 0, 0}, pb[4] = {0, 0, 0, 0};
         const bool in_band = k >= (int)p.bin_lo && k < (int)p.bin_hi;
 #define SONO_BIN(B, ZR, ZI, PR, PI)                                                              \
   {                                                                                              \
@@ -326,8 +328,8 @@ __global__ __launch_bounds__(kWaves * 64) void stft512_kernel(StftParams p, Fast
     const float ma = __builtin_fmaf(ar, ar, ai * ai);                                            \
     const float mb = __builtin_fmaf(br, br, bi * bi);                                            \
     if constexpr (FEAT) { /* a lane visits the bins of a frame in ascending order */             \
-      if (in_band && ma > best[2 * q]) { best[2 * q] = ma; kbest[2 * q] = k + B; }               \
-      if (in_band && mb > best[2 * q + 1]) { best[2 * q + 1] = mb; kbest[2 * q + 1] = k + B; }   \
+      pa[B] = ma;                                                                                \
+      pb[B] = mb;                                                                                \
     } else {                                                                                     \
       wa = put_index<PLUGIN, B>(ma, fs, wa);                                                     \
       wb = put_index<PLUGIN, B>(mb, fs, wb);                                                     \
@@ -338,6 +340,18 @@ __global__ __launch_bounds__(kWaves * 64) void stft512_kernel(StftParams p, Fast
         SONO_BIN(2, z23.x, z23.y, q23.x, q23.y)
         SONO_BIN(3, z23.z, z23.w, q23.z, q23.w)
 #undef SONO_BIN
+        if constexpr (FEAT) {
+          if (in_band) {  // (one branch per bin quad; selects inside)
+#pragma unroll
+            for (int B = 0; B < 4; ++B) {
+              next[2 * q] = __builtin_amdgcn_fmed3f(pa[B], best[2 * q], next[2 * q]);
+              next[2 * q + 1] = __builtin_amdgcn_fmed3f(pb[B], best[2 * q + 1], next[2 * q + 1]);
+              const bool ga = pa[B] > best[2 * q], gb = pb[B] > best[2 * q + 1];
+              best[2 * q] = ga ? pa[B] : best[2 * q]; kbest[2 * q] = ga ? k + B : kbest[2 * q];
+              best[2 * q + 1] = gb ? pb[B] : best[2 * q + 1]; kbest[2 * q + 1] = gb ? k + B : kbest[2 * q + 1];
+            }
+          }
+        }
         if (!FEAT && in_band) {
           const uint64_t fa = fb + 2 * q;
           const uint64_t row_a = (p.col0 + fa) * p.out_bins, row_b = row_a + p.out_bins;
@@ -352,17 +366,17 @@ __global__ __launch_bounds__(kWaves * 64) void stft512_kernel(StftParams p, Fast
       // larger |X|^2 wins, equal values go to the lower bin
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
+        reduce_peak<32>(best[i], kbest[i], next[i]);
+      }
 #pragma unroll
-        for (int m = 1; m < 32; m <<= 1) {
-          const float o = __shfl_xor(best[i], m, 64);
-          const int ko = __shfl_xor(kbest[i], m, 64);
-          if (o > best[i] || (o == best[i] && ko < kbest[i])) { best[i] = o; kbest[i] = ko; }
-        }
+      for (int i = 0; i < 4; ++i) {
         const uint64_t fr = fb + i;
         if (l == 0 && fr >= f0 && fr < p.nframes) {
+          // reserved[0] = 1: float32 cannot tell; the exact-arithmetic pass that follows recomputes the record
           sono_frame_feature r{};
           r.peak_bin = kbest[i];
           r.peak_idx = (uint8_t)put_index<PLUGIN, 0>(best[i], fs, 0);
+          r.reserved[0] = feature_uncertain(best[i], next[i], best[i ^ 1], __builtin_fmaf(__log2f(best[i]), fs.a, fs.b), fs) ? 1 : 0;
           reinterpret_cast<sono_frame_feature*>(p.out)[p.col0 + fr] = r;
         }
       }
@@ -590,6 +604,7 @@ int launch_stft_fast512(const StftParams& p, void* stream_v) {
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_v);
   FastScale fs = make_fast_scale(p.scale_mode, p.n, p.gain_db, p.range_db);
   fs.b -= 2.0f * fs.a;  // the pair separation leaves 2*X: |2X|^2 = 4|X|^2
+  fs.xtalk = (float)p.pair_asym;
   const int cus = device_cu_count();
   const uint64_t nunits = (p.nframes + 7) / 8;
   const uint64_t need = (nunits + kWaves - 1) / kWaves;

@@ -79,7 +79,22 @@ __global__ __launch_bounds__(kThreads) void stft_general_kernel(StftParams p, Fa
   const uint32_t nb = p.bin_hi - p.bin_lo;
   const double two_over_n = 2.0 / (double)n;
 
-  for (uint32_t fl = 0; fl < count; ++fl) {
+  // fix-up pass over a SONO_OUT_FEATURES output of a float32 kernel (frames_per_block == kThreads): only the
+  // records it marked (reserved[0] != 0) are recomputed
+  __shared__ uint32_t s_todo[kThreads];
+  __shared__ uint32_t s_ntodo;
+  const bool fixup = p.fixup != 0;
+  if (fixup) {
+    if (tid == 0) s_ntodo = 0;
+    __syncthreads();
+    if (tid < count && reinterpret_cast<const sono_frame_feature*>(p.out)[p.col0 + first + tid].reserved[0] != 0)
+      s_todo[atomicAdd(&s_ntodo, 1u)] = tid;
+    __syncthreads();
+    if (tid == 0 && s_ntodo && p.tile_scratch) atomicAdd(reinterpret_cast<uint32_t*>(p.tile_scratch) + 1, s_ntodo);  // statistics only
+  }
+  const uint32_t rounds = fixup ? s_ntodo : count;
+  for (uint32_t it = 0; it < rounds; ++it) {
+    const uint32_t fl = fixup ? s_todo[it] : it;
     const uint64_t frame = p.frame0 + first + fl;
     const uint64_t a = frame * p.hop;
     // window, spectrogramWorker.js:61-64 / spectrogram.esm.js:172-174: float32(x*w) at the
@@ -276,7 +291,7 @@ int launch_stft_general(const StftParams& p, bool exact_f64, void* stream_v) {
     if (ft < 1) ft = 1;
     lds += (size_t)ft * stride;
   } else {
-    ft = 8;
+    ft = p.fixup ? kThreads : 8;
   }
   if (p.fb_bin) {
     if (p.scale_mode != SONO_SCALE_PLUGIN_DB || !p.fb_w0 || !p.fb_w1) return SONO_ERR_ARG;
@@ -297,7 +312,7 @@ int launch_stft_general(const StftParams& p, bool exact_f64, void* stream_v) {
     if (p.in_kind == SONO_IN_I16) SONO_LAUNCH(float, int16_t); else SONO_LAUNCH(float, float);
   }
 #undef SONO_LAUNCH
-  note_kernel(exact_f64 ? "stft_general_kernel<double>" : "stft_general_kernel<float>");
+  note_kernel(p.fixup ? "stft_general_kernel<double,fixup>" : exact_f64 ? "stft_general_kernel<double>" : "stft_general_kernel<float>");
   return hipGetLastError() == hipSuccess ? SONO_OK : SONO_ERR_DEVICE;
 }
 

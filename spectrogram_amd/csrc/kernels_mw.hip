@@ -105,6 +105,7 @@ __global__ __launch_bounds__((1 << LOG2N) / 16 * G, 4) void stft_mw_kernel(StftP
   constexpr int kWavesPerGroup = TN > 64 ? TN / 64 : 1;
   __shared__ float s_best[FEAT ? G * kWavesPerGroup * 2 : 1];   // FEAT, transforms wider than a wavefront:
   __shared__ int s_bestk[FEAT ? G * kWavesPerGroup * 2 : 1];    // per-wavefront peaks of the two frames
+  __shared__ float s_next[FEAT ? G * kWavesPerGroup * 2 : 1];   // ... and their runners-up
   static_assert(CB >= 1 && CB <= 4, "512 to 4096 points");
   constexpr int kPlane = N + N / 32;
   __shared__ float s_re_all[G][kPlane], s_im_all[G][kPlane];
@@ -213,6 +214,7 @@ __global__ __launch_bounds__((1 << LOG2N) / 16 * G, 4) void stft_mw_kernel(StftP
     const float mag_scale = PLUGIN ? 1.0f / (float)N : 0.5f;  // the pair separation leaves 2*X; plugin: 2/N * |X|
     float best_a = -1.0f, best_b = -1.0f;                     // FEAT: this thread's largest |X|^2 so far and its bin
     int kbest_a = (int)p.bin_lo, kbest_b = (int)p.bin_lo;
+    float next_a = -1.0f, next_b = -1.0f;                     // FEAT: the runner-up (decides whether float32 can tell)
 #pragma unroll
     for (int m = 0; m < (N / 8) / TN; ++m) {
       const int k = 4 * (t + TN * m);
@@ -230,6 +232,8 @@ __global__ __launch_bounds__((1 << LOG2N) / 16 * G, 4) void stft_mw_kernel(StftP
     const float ma = __builtin_fmaf(ar, ar, ai * ai);                          \
     const float mb = __builtin_fmaf(br, br, bi * bi);                          \
     if constexpr (FEAT) { /* a thread visits its bins in ascending order */    \
+      next_a = __builtin_amdgcn_fmed3f(ma, best_a, next_a);                    \
+      next_b = __builtin_amdgcn_fmed3f(mb, best_b, next_b);                    \
       if (ma > best_a) { best_a = ma; kbest_a = k + B; }                       \
       if (mb > best_b) { best_b = mb; kbest_b = k + B; }                       \
     } else if constexpr (FLT) {                                                \
@@ -256,41 +260,49 @@ __global__ __launch_bounds__((1 << LOG2N) / 16 * G, 4) void stft_mw_kernel(StftP
     if constexpr (FEAT) {
       // larger |X|^2 wins, equal values go to the lower bin: first across the lanes of the transform's wavefront
       // (or its 32-lane half at 512 points), then across its wavefronts through LDS
-      auto take = [](float& bm, int& bk, float om, int ok) {
+      auto take = [](float& bm, int& bk, float& nx, float om, int ok, float on) {
+        nx = __builtin_fmaxf(__builtin_fminf(bm, om), __builtin_fmaxf(nx, on));
         if (om > bm || (om == bm && ok < bk)) { bm = om; bk = ok; }
       };
 #pragma unroll
       for (int msk = 1; msk < (TN < 64 ? TN : 64); msk <<= 1) {
-        take(best_a, kbest_a, __shfl_xor(best_a, msk, 64), __shfl_xor(kbest_a, msk, 64));
-        take(best_b, kbest_b, __shfl_xor(best_b, msk, 64), __shfl_xor(kbest_b, msk, 64));
+        take(best_a, kbest_a, next_a, __shfl_xor(best_a, msk, 64), __shfl_xor(kbest_a, msk, 64), __shfl_xor(next_a, msk, 64));
+        take(best_b, kbest_b, next_b, __shfl_xor(best_b, msk, 64), __shfl_xor(kbest_b, msk, 64), __shfl_xor(next_b, msk, 64));
       }
       if constexpr (kWavesPerGroup > 1) {
         const int wv = t >> 6;
         if ((t & 63) == 0) {
           s_best[(grp * kWavesPerGroup + wv) * 2] = best_a;     s_bestk[(grp * kWavesPerGroup + wv) * 2] = kbest_a;
           s_best[(grp * kWavesPerGroup + wv) * 2 + 1] = best_b; s_bestk[(grp * kWavesPerGroup + wv) * 2 + 1] = kbest_b;
+          s_next[(grp * kWavesPerGroup + wv) * 2] = next_a;     s_next[(grp * kWavesPerGroup + wv) * 2 + 1] = next_b;
         }
         __syncthreads();
         if (t == 0) {
 #pragma unroll
           for (int v = 1; v < kWavesPerGroup; ++v) {
-            take(best_a, kbest_a, s_best[(grp * kWavesPerGroup + v) * 2], s_bestk[(grp * kWavesPerGroup + v) * 2]);
-            take(best_b, kbest_b, s_best[(grp * kWavesPerGroup + v) * 2 + 1], s_bestk[(grp * kWavesPerGroup + v) * 2 + 1]);
+            take(best_a, kbest_a, next_a, s_best[(grp * kWavesPerGroup + v) * 2], s_bestk[(grp * kWavesPerGroup + v) * 2],
+                 s_next[(grp * kWavesPerGroup + v) * 2]);
+            take(best_b, kbest_b, next_b, s_best[(grp * kWavesPerGroup + v) * 2 + 1], s_bestk[(grp * kWavesPerGroup + v) * 2 + 1],
+                 s_next[(grp * kWavesPerGroup + v) * 2 + 1]);
           }
         }
       }
       if (t == 0) {
+        // reserved[0] = 1: float32 cannot tell; the exact-arithmetic pass that follows recomputes the record
         sono_frame_feature* ft = reinterpret_cast<sono_frame_feature*>(p.out) + (p.col0 + f0);
+        const float ta = __builtin_fmaf(__log2f(best_a), fs.a, fs.b), tb = __builtin_fmaf(__log2f(best_b), fs.a, fs.b);
         if (st_a) {
           sono_frame_feature r{};
           r.peak_bin = kbest_a;
           r.peak_idx = (uint8_t)put_index<PLUGIN, 0>(best_a, fs, 0);
+          r.reserved[0] = feature_uncertain(best_a, next_a, best_b, ta, fs) ? 1 : 0;
           ft[0] = r;
         }
         if (active) {
           sono_frame_feature r{};
           r.peak_bin = kbest_b;
           r.peak_idx = (uint8_t)put_index<PLUGIN, 0>(best_b, fs, 0);
+          r.reserved[0] = feature_uncertain(best_b, next_b, best_a, tb, fs) ? 1 : 0;
           ft[1] = r;
         }
       }
@@ -325,6 +337,7 @@ int launch_stft_mw(const StftParams& p, void* stream_v) {
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_v);
   FastScale fs = make_fast_scale(p.scale_mode, p.n, p.gain_db, p.range_db);
   fs.b -= 2.0f * fs.a;  // the pair separation leaves 2*X
+  fs.xtalk = (float)p.pair_asym;
   fs.db_off -= 2.0f * 3.0102999566f;
   const uint64_t npairs = (p.nframes + 1) / 2;
   const int cus = device_cu_count();

@@ -41,18 +41,60 @@ __device__ __forceinline__ uint32_t plugin_index_exact(float m, double gain, dou
   return (uint32_t)((long long)trunc(v) & 255);
 }
 
+// Feature pass, reduction of per-lane (largest |X|^2, its bin, runner-up) over the `width` lanes that share a frame:
+// larger value wins, equal values go to the lower bin (the strict-> first-wins rule over ascending bins); the
+// frame's runner-up is the largest of the losers' bests and the winner's own runner-up.
+template <int WIDTH>
+__device__ __forceinline__ void reduce_peak(float& best, int& kbest, float& next) {
+  const float mine = best;
+  const int kmine = kbest;
+#pragma unroll
+  for (int m = 1; m < WIDTH; m <<= 1) {
+    const float o = __shfl_xor(best, m, 64);
+    const int ko = __shfl_xor(kbest, m, 64);
+    const bool g = o > best || (o == best && ko < kbest);
+    best = g ? o : best;
+    kbest = g ? ko : kbest;
+  }
+  float c = (kmine == kbest) ? next : mine;   // the winning lane offers its runner-up, every other lane its best
+#pragma unroll
+  for (int m = 1; m < WIDTH; m <<= 1) c = __builtin_fmaxf(c, __shfl_xor(c, m, 64));
+  next = c;
+}
+
 // ---------------------------------------------------------------- fast (float32) quantisers
 // Both work from |X|^2 so no square root is needed: log10|X| = 0.5*log10(2)*log2(|X|^2).
 struct FastScale {
   float a, b;     // t = log2(|X|^2) * a + b
   float t_floor;  // plugin: t at the 1e-12 magnitude floor (r = -240 dB)
   float db_off;   // dB = 10*log10(2) * log2(|X|^2) + db_off
+  float xtalk;    // feature pass: share of the partner frame's |X| that may leak into a bin (two frames per transform)
+  float tscale;   // feature pass: |d t / d ln(|X|^2)| = |a| / ln 2
   uint32_t mode;
 };
+
+// Feature pass of the float32 kernels: a frame's record is exact unless the float32 arithmetic cannot tell.  With
+// P1 >= P2 the two largest |X|^2 of the band, Pp the largest of the frame transformed with it, and t the quantiser
+// argument of P1: the float32 powers are within kTieRel (measured error < 1e-6; 40x margin) plus the pair's
+// cross-talk of the reference's, so the argmax is safe if P1 - P2 exceeds that, and the colour index is safe if t
+// is further from an integer than the same error scaled by d t / d ln P, plus the error of v_log_f32.  Anything
+// else is marked and recomputed in the exact arithmetic (launch_features_fixup).
+constexpr float kTieRel = 4e-5f;
+__device__ __forceinline__ bool feature_uncertain(float p1, float p2, float pp, float t, const FastScale& s) {
+  if (!(p1 > 0.0f)) return false;  // an all-zero band is all-zero in every arithmetic: first bin, index from |X| = 0
+  const float q = s.xtalk * __builtin_amdgcn_sqrtf(pp) * __builtin_amdgcn_rsqf(p1);   // |leak| / |X|: power error 2q + q^2
+  const float rel = __builtin_fmaf(q, 2.0f + q, kTieRel);  // relative error bound of P1 (and, in units of P1, of P2)
+  const bool tie = p1 - p2 <= 2.0f * rel * p1;
+  const float fr = __builtin_amdgcn_fractf(t);
+  const float dt = __builtin_fmaf(s.tscale, rel, 2e-4f);
+  const bool edge = !(fr > dt && fr < 1.0f - dt) && t > -1.0f && t < 257.0f;
+  return tie || edge;
+}
 
 __host__ __device__ inline FastScale make_fast_scale(uint32_t mode, uint32_t n, double gain, double range) {
   FastScale s;
   s.mode = mode;
+  s.xtalk = 0.0f;
   const double l10_2 = 0.30102999566398119521;
   if (mode == SONO_SCALE_WORKER_LOG5) {
     s.a = (float)(255.0 * 0.5 * l10_2 / 5.0);  // 255 * log10|X| / 5
@@ -67,6 +109,7 @@ __host__ __device__ inline FastScale make_fast_scale(uint32_t mode, uint32_t n, 
     s.t_floor = (float)((-240.0 + gain) * 255.0 / range + 256.0);
     s.db_off = (float)(10.0 * l10_2 * lg);
   }
+  s.tscale = 1.4427f * (s.a < 0 ? -s.a : s.a);
   return s;
 }
 

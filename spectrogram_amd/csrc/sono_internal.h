@@ -41,11 +41,15 @@ struct StftParams {
                           // transforming two real frames as one complex frame separates them to float32 accuracy; the
                           // plugin's recurrence factors are not (1e-5 off at 1024 points, 3e-5 at 4096), which is harmless
                           // for colour indices and peaks but not for float32 outputs held to 0.01 dB
+  double pair_asym;       // that largest deviation from conjugate symmetry itself (0 for exact roots): a bin of one frame of a
+                          // pair carries this fraction of the other frame's value at the same bin
   const int32_t* fb_bin;  // device: non-linear frequency scale, first tap of output bin i (n/2 entries), or nullptr = linear
   const double* fb_w0;    // device: weight of bin fb_bin[i]
   const double* fb_w1;    // device: weight of bin fb_bin[i] + 1
   void* tile_scratch;     // device: fast_rgba_scratch_bytes() of scratch for the fused RGBA output, or nullptr
   uint32_t scale_mode, out_kind, in_kind;
+  uint32_t fixup;         // != 0: recompute only the feature records a float32 kernel marked (reserved[0] != 0); for
+                          // launch_features_fixup the capacity of the queue's list
   double gain_db, range_db;
 };
 
@@ -70,6 +74,12 @@ void build_fast_table_2048(std::vector<float>& t);
 // (returns 1 if it does not serve this size / layout).
 int launch_stft_mw(const StftParams& p, void* hip_stream);
 bool mw_u8_available(const StftParams& p);
+// kernels_exact.hip: recomputes, in the exact arithmetic, the records of a SONO_OUT_FEATURES output that a fast kernel
+// marked as too close to call (reserved[0] != 0) and clears the mark.  `p.twiddles` must be the double2 table.
+// `p.tile_scratch` is the pass's queue of features_fixup_queue_bytes(p.fixup) bytes, p.fixup the capacity of its list.
+int launch_features_fixup(const StftParams& p, void* hip_stream);
+bool features_fixup_available(const StftParams& p);
+uint64_t features_fixup_queue_bytes(uint32_t capacity);
 // kernels_exact.hip: the exact arithmetic for 1024-point frames, two in-register passes (returns 1 if it does not
 // serve this launch; results are bit-identical to launch_stft_general(p, true, ...)).
 int launch_stft_exact(const StftParams& p, void* hip_stream);

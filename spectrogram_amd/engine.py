@@ -147,6 +147,10 @@ class Engine:
         """Kernels the most recent transform call enqueued (sono_kernel_route)."""
         return self._lib.sono_kernel_route(self._ctx).decode()
 
+    def features_recomputed(self):
+        """Records of the last float32 feature launch that were recomputed in the exact arithmetic."""
+        return int(self._lib.sono_features_recomputed(self._ctx))
+
     def reserve(self, n_samples):
         """Size the staging buffers for host calls of up to n_samples (sono_reserve)."""
         self._check(self._lib.sono_reserve(self._ctx, int(n_samples)))

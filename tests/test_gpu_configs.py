@@ -1,0 +1,232 @@
+"""The benchmark configurations at their own sizes, against the CPU checker.
+
+The checker cannot transform an hour of audio in seconds, so each test pins a head (and a tail) of the result
+to the checker and carries that to the full size through a size-independent property: a periodic signal gives
+periodic results; the image is the colour map applied to the indices the index output of the same arithmetic
+gives; spans of a recording reproduce the whole.  Tolerances as everywhere: colour indices within 1 LSB in the
+float32 arithmetic, integer feature records bit-exact.
+"""
+import numpy as np
+import pytest
+
+import oracle
+from conftest import golden_store
+from spectrogram_amd import _ffi as F
+from spectrogram_amd import engine as E
+from spectrogram_amd import sharding
+
+pytestmark = pytest.mark.gpu
+G = golden_store()
+
+
+def plugin_engine(n, hop, arith=F.ARITH_FAST_F32, out_kind=F.OUT_U8_INDEX, **kw):
+    return E.Engine(fft_n=n, hop=hop, window_id=F.WINDOW_IDS["hann"], gain_db=20.0, range_db=80.0, scale_mode=F.SCALE_PLUGIN_DB,
+                    frame_rule=F.FRAMES_PLUGIN_STRICT, twiddle_mode=F.TW_PLUGIN_RECURRENCE, arith=arith, out_kind=out_kind, **kw)
+
+
+def worker_engine(n, hop, arith=F.ARITH_FAST_F32, out_kind=F.OUT_RGBA8, **kw):
+    return E.Engine(fft_n=n, hop=hop, window_id=F.WIN_WORKER_HANN, scale_mode=F.SCALE_WORKER_LOG5,
+                    frame_rule=F.FRAMES_WORKER_COMPAT, twiddle_mode=F.TW_ACCURATE, arith=arith, out_kind=out_kind, **kw)
+
+
+def within_one_step(img, want_idx, lut):
+    """Every pixel is the colour of the checker's index or of a neighbouring one (cyclic at the plugin's wrap)."""
+    l4 = lut.reshape(256, 4)
+    w = want_idx.astype(np.int16)
+    ok = np.zeros(w.shape, bool)
+    for dlt in (-1, 0, 1):
+        ok |= np.all(img == l4[(w + dlt) % 256], axis=-1)
+    return ok.all(), np.all(img == l4[w], axis=-1).mean()
+
+
+# ------------------------------------------------------------------ FFT 4096, 93.75 % overlap, 15-120 kHz, RGBA
+def test_fft4096_band_crop_rgba_fast_against_checker():
+    """FFT 4096, hop 256, bins 160..1279 (15-120 kHz at 384 kHz), float32 arithmetic, RGBA through the default
+    colour map: the route the benchmark variant times.  On the reference's bat signal and on a seeded signal of
+    2 100 frames every pixel must be the colour of the checker's index +-1, and >= 99 % equal."""
+    n, hop, lo, hi = 4096, 256, 160, 1280
+    sy, sh = E.plugin_crop(n // 2, 384000, 15000, 120000)
+    assert (n // 2 - sy - sh, n // 2 - sy) == (lo, hi)
+    lut = E.plugin_lut(G.colormap("default"))
+    rng = np.random.default_rng(4096)
+    L = n + hop * 2100 + 5
+    t = np.arange(L, dtype=np.float64)
+    seeded = (rng.standard_normal(L) * 0.02).astype(np.float32)
+    seeded += (0.5 * np.sin(0.35 * t + 3e-7 * t * t) * (np.sin(2e-4 * t) > 0)).astype(np.float32)
+    for x in (G.signal("bat"), seeded):
+        ref = oracle.plugin_get_frequencies(x, n, n - hop)
+        with plugin_engine(n, hop, out_kind=F.OUT_RGBA8, bin_lo=lo, bin_hi=hi) as eng:
+            eng.set_colormap(lut)
+            img = eng.stft(x)
+            route = eng.kernel_route()
+        assert "4096" in route and "general" not in route, route
+        want = ref[:, lo:hi].T[::-1]
+        assert img.shape == want.shape + (4,)
+        ok, same = within_one_step(img, want, lut)
+        assert ok and same >= 0.99, (route, same)
+
+
+def test_fft4096_band_crop_rgba_at_benchmark_size():
+    """The same route at the benchmark's size (60 s x 384 kHz: 89 984 frames, 100 MB of indices = several chunks of
+    the index buffer): the image must be the colour map applied to the [frame][bin] indices the same arithmetic
+    writes (flipped, transposed) everywhere; a signal of period 64 hops gives columns of period 64; the head
+    equals the checker's within one step."""
+    torch = pytest.importorskip("torch")
+    n, hop, lo, hi, pf = 4096, 256, 160, 1280, 64
+    period = hop * pf
+    L = 60 * 384000
+    rng = np.random.default_rng(41)
+    base = (rng.standard_normal(period) * 0.05).astype(np.float32)
+    base[2000:9000] += (0.5 * np.sin(np.arange(7000) * 0.6 + 2e-5 * np.arange(7000) ** 2)).astype(np.float32)
+    dev = torch.device("cuda:0")
+    x = torch.from_numpy(base).to(dev).repeat(L // period + 1)[:L].contiguous()
+    lut = E.plugin_lut(G.colormap("default"))
+    with plugin_engine(n, hop, out_kind=F.OUT_RGBA8, bin_lo=lo, bin_hi=hi) as eng, \
+            plugin_engine(n, hop, out_kind=F.OUT_U8_INDEX, bin_lo=lo, bin_hi=hi) as eng8:
+        eng.set_colormap(lut)
+        g = eng.geometry(L)
+        assert (g.frames, g.bins) == (89984, 1120)
+        img = torch.empty((g.bins, g.width, 4), dtype=torch.uint8, device=dev)
+        idx = torch.empty((g.frames, g.bins), dtype=torch.uint8, device=dev)
+        torch.cuda.synchronize()
+        eng.stft_device(x.data_ptr(), L, img.data_ptr(), img.numel())
+        eng8.stft_device(x.data_ptr(), L, idx.data_ptr(), idx.numel())
+        px = img.view(torch.int32).view(g.bins, g.width)
+        lut32 = torch.from_numpy(lut.view(np.int32).copy()).to(dev)
+        assert bool((px == lut32[idx.long()].t().flip(0)).all())
+        whole = (g.frames // pf) * pf
+        v = idx[:whole].view(-1, pf, g.bins)
+        assert bool((v == v[0:1]).all())
+        head = img[:, :pf].cpu().numpy()
+    ref = oracle.plugin_get_frequencies(np.tile(base, 2)[:period + n + 1], n, n - hop)[:pf]
+    ok, same = within_one_step(head, ref[:, lo:hi].T[::-1], lut)
+    assert ok and same >= 0.99
+
+
+# ------------------------------------------------------------------ the feature pass on the 1 h recording
+def test_feature_pass_at_recording_size_and_span_merge():
+    """1 h x 384 kHz, FFT 1024, hop 256, SONO_OUT_FEATURES in the float32 arithmetic (with its exact fix-up pass):
+    records of a period-64-hops signal repeat every 64 frames and the first 64 are the checker's, bit for bit;
+    segmenting all 5.4 M records gives what the periodic structure predicts; the recording cut into 8 spans
+    (split_recording), each transformed on its own and segmented with min_frames = 1, then merged with the real
+    minimum (merge_calls), gives the same calls."""
+    torch = pytest.importorskip("torch")
+    n, hop, pf = 1024, 256, 64
+    period = hop * pf
+    L = 3600 * 384000
+    rng = np.random.default_rng(55)
+    base = (rng.standard_normal(period) * 0.01).astype(np.float32)
+    t = np.arange(1920, dtype=np.float64)          # one 5 ms down-sweeping pulse per period, Hann-shaped
+    base[4000:5920] += (0.3 * 0.5 * (1 - np.cos(2 * np.pi * t / 1920)) * np.sin(1.2 * t - 1.6e-4 * t * t)).astype(np.float32)
+    dev = torch.device("cuda:0")
+    x = torch.from_numpy(base).to(dev).repeat(L // period + 1)[:L].contiguous()
+    thr, min_frames = 190, 3
+    with plugin_engine(n, hop, out_kind=F.OUT_FEATURES, bin_lo=40, bin_hi=400) as eng:
+        g = eng.geometry(L)
+        assert g.frames == 5399996
+        out = torch.empty((g.frames, 8), dtype=torch.uint8, device=dev)
+        torch.cuda.synchronize()
+        eng.stft_device(x.data_ptr(), L, out.data_ptr(), out.numel())
+        assert "fixup" in eng.kernel_route()
+        whole = (g.frames // pf) * pf
+        v = out[:whole].view(-1, pf, 8)
+        assert bool((v == v[0:1]).all())
+        ft = out.cpu().numpy().view(F.FEATURE_DTYPE).reshape(-1)
+        # spans on their own (pointer offsets into the resident recording)
+        spans = sharding.split_recording(L, n, hop, 8, F.FRAMES_PLUGIN_STRICT)
+        parts = []
+        for s in spans:
+            so = torch.empty((s["frames"], 8), dtype=torch.uint8, device=dev)
+            eng.stft_device(x.data_ptr() + 4 * s["sample_start"], s["sample_count"], so.data_ptr(), so.numel())
+            fs = so.cpu().numpy().view(F.FEATURE_DTYPE).reshape(-1)
+            parts.append(E.segment_calls(fs, thr, 1, first_frame=s["first_frame"]))
+    assert not ft["reserved"].any()
+    # head against the checker
+    idx, mags, _, _ = oracle.plugin_get_frequencies(np.tile(base, 2)[:period + n + 1], n, n - hop, want_mags=True)
+    refp = oracle.frame_peaks_f32(mags[:pf], 40, 400)
+    assert np.array_equal(ft["peak_bin"][:pf], refp)
+    assert np.array_equal(ft["peak_idx"][:pf], idx[np.arange(pf), refp])
+    # segmentation of the whole, predicted from the head
+    calls = E.segment_calls(ft, thr, min_frames)
+    head_calls = E.segment_calls(ft[:pf], thr, min_frames)
+    assert len(head_calls) >= 1 and head_calls["start_frame"][0] > 0 and head_calls["end_frame"][-1] < pf - 1
+    assert len(calls) == len(head_calls) * (g.frames // pf) + len(E.segment_calls(ft[whole:], thr, min_frames))
+    k = len(head_calls)
+    assert np.array_equal(calls["peak_bin"][:k], head_calls["peak_bin"])
+    assert np.array_equal(calls["start_frame"][k:2 * k], head_calls["start_frame"] + pf)
+    # 8 spans, stitched
+    merged = sharding.merge_calls(parts, min_frames=min_frames)
+    assert merged.tobytes() == calls.tobytes()
+
+
+# ------------------------------------------------------------------ per-file batch: 5 s x 500 kHz int16 files
+def test_file_pipeline_at_file_size_against_checker():
+    """Three 2.5 M-sample int16 files (5 s x 500 kHz) through the overlapped per-file pipeline, worker render to RGBA:
+    the first and the last 64 columns of every image are within one step of the checker's render of the same
+    samples, and each image equals the synchronous call's."""
+    from spectrogram_amd.sharding import FilePipeline
+    n, hop, L = 1024, 256, 2_500_000
+    kw = dict(fft_n=n, hop=hop, window_id=F.WIN_WORKER_HANN, scale_mode=F.SCALE_WORKER_LOG5, frame_rule=F.FRAMES_WORKER_COMPAT,
+              twiddle_mode=F.TW_ACCURATE, arith=F.ARITH_FAST_F32, out_kind=F.OUT_RGBA8, in_kind=F.IN_I16)
+    files = []
+    for i in range(3):
+        rng = np.random.default_rng(500 + i)
+        x = rng.standard_normal(L) * 0.01
+        for p0 in range(20000 * (i + 1), L - 3000, 40000):          # 5 ms pulses every 80 ms, 80 -> 35 kHz
+            t = np.arange(2500, dtype=np.float64)
+            x[p0:p0 + 2500] += 0.3 * np.hanning(2500) * np.sin(2 * np.pi * (80e3 * t / 5e5 - 0.5 * 45e3 / 2500 * t * t / 5e5))
+        files.append(("file%d" % i, np.round(np.clip(x, -1, 1) * 32767).astype(np.int16)))
+    lut = E.worker_lut(G.colormap("default"))
+    with FilePipeline(L, slots=3, **kw) as pipe:
+        for e in pipe.engines:
+            e.set_colormap(lut)
+        got = list(pipe.run(files))
+    width = -(-(L - n) // hop)
+    frames = (L - n) // hop + 1
+    assert frames == width == 9762
+    with E.Engine(**kw) as eng:
+        eng.set_colormap(lut)
+        for (tag, img), (tag0, q) in zip(got, files):
+            assert tag == tag0 and img.shape == (n // 2, width, 4)
+            assert np.array_equal(img, eng.stft(q))
+            xf = (q.astype(np.float32) / 32768.0).astype(np.float32)
+            head = oracle.worker_render(xf[:n + hop * 64 + 1], n, 75.0, None)[..., 0]      # grey render = index image
+            tail = oracle.worker_render(xf[(frames - 64) * hop:], n, 75.0, None)[..., 0]
+            assert head.shape[1] >= 64 and tail.shape[1] == 64
+            for part, ref_idx in ((img[:, :64], head[:, :64]), (img[:, -64:], tail)):
+                ok, same = within_one_step(part, ref_idx, lut)
+                assert ok and same >= 0.99, tag
+
+
+def test_feature_fixup_when_most_frames_are_doubtful():
+    """A tone half-way between two bins makes the two top bins equal up to rounding in EVERY frame, so the float32
+    feature kernel marks all 1.8 M frames of a 20-minute recording -- more than the fix-up pass can list (2^20), which
+    exercises its scan for the rest.  Records must repeat with the signal's period (8 hops) and equal the checker's."""
+    torch = pytest.importorskip("torch")
+    n, hop, k = 1024, 256, 200
+    L = 1200 * 384000
+    period = 8 * hop
+    t = np.arange(period, dtype=np.float64)
+    base = (0.5 * np.sin(2 * np.pi * (k + 0.5) / n * t)).astype(np.float32)
+    dev = torch.device("cuda:0")
+    x = torch.from_numpy(base).to(dev).repeat(L // period + 1)[:L].contiguous()
+    for eng in (plugin_engine(n, hop, out_kind=F.OUT_FEATURES), worker_engine(n, hop, out_kind=F.OUT_FEATURES)):
+        with eng:
+            g = eng.geometry(L)
+            out = torch.empty((g.frames, 8), dtype=torch.uint8, device=dev)
+            torch.cuda.synchronize()
+            eng.stft_device(x.data_ptr(), L, out.data_ptr(), out.numel())
+            assert eng.features_recomputed() > (1 << 20)
+            whole = (g.frames // 8) * 8
+            v = out[:whole].view(-1, 8, 8)
+            assert bool((v == v[0:1]).all())
+            ft = out[:8].cpu().numpy().view(F.FEATURE_DTYPE).reshape(-1)
+        assert not ft["reserved"].any()
+        head = np.tile(base, 3)[:period + n + 1]
+        if eng.cfg.scale_mode == F.SCALE_PLUGIN_DB:
+            idx, mags, _, _ = oracle.plugin_get_frequencies(head, n, n - hop, want_mags=True)
+        else:
+            mags, idx = oracle.worker_magnitudes(head, n, hop, 8)
+        refp = oracle.frame_peaks_f32(mags[:8])
+        assert set(refp) <= {k, k + 1}
+        assert np.array_equal(ft["peak_bin"], refp) and np.array_equal(ft["peak_idx"], idx[np.arange(8), refp])

@@ -74,8 +74,10 @@ int main(int argc, char** argv) {
   unsigned sum = 0;
   for (uint8_t b : head) sum += b;
   const double algo = (double)L * 4 + (double)ob;
-  printf("{\"samples\": %llu, \"ms_per_step\": %.4f, \"msamples_per_s\": %.1f, \"algorithmic_gbps\": %.1f, \"hbm_frac\": %.4f, \"checksum\": %u}\n",
-         (unsigned long long)L, ms, (double)L / ms / 1e3, algo / ms / 1e6, algo / ms / 1e6 / 8000.0, sum);
+  printf("{\"samples\": %llu, \"ms_per_step\": %.4f, \"msamples_per_s\": %.1f, \"algorithmic_gbps\": %.1f, \"hbm_frac\": %.4f, \"checksum\": %u, "
+         "\"route\": \"%s\", \"recomputed\": %lld}\n",
+         (unsigned long long)L, ms, (double)L / ms / 1e3, algo / ms / 1e6, algo / ms / 1e6 / 8000.0, sum, sono_kernel_route(c),
+         (long long)sono_features_recomputed(c));
   sono_device_free(c, dx);
   sono_device_free(c, dout);
   sono_destroy(c);
