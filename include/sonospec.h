@@ -208,6 +208,77 @@ int sono_worker_lut(const double* colormap_rgba, uint8_t* lut_rgba);
  * splits one recording into chunks merges it with a run starting at frame 0 of the next chunk. */
 int64_t sono_segment_calls(const sono_frame_feature* features, uint64_t frames, uint32_t threshold, uint32_t min_frames,
                            uint64_t first_frame, sono_call* out, uint64_t capacity);
+/* ---- from calls to species: the auto-ID panel's fields and the matcher (host, no GPU) ----------------------- */
+
+/* The fourteen numeric fields autoIdHK tests, in its order (modules/autoid_HK.js:216-221).  kHz and ms. */
+typedef enum sono_autoid_field {
+  SONO_F_HIGHEST = 0, SONO_F_LOWEST = 1, SONO_F_KNEE = 2, SONO_F_HEEL = 3, SONO_F_START = 4, SONO_F_END = 5,
+  SONO_F_CF_START = 6, SONO_F_CF_END = 7, SONO_F_DURATION = 8, SONO_F_BANDWIDTH = 9, SONO_F_KNEE_LOW_TIME = 10,
+  SONO_F_KNEE_LOW_BW = 11, SONO_F_HEEL_LOW_BW = 12, SONO_F_KNEE_HEEL_BW = 13
+} sono_autoid_field;
+#define SONO_AUTOID_FIELDS 14
+#define SONO_AUTOID_ABSENT INT32_MIN
+
+/* The `data` object autoIdHK receives (autoIdPanel.js:1442-1462).  A NaN field is an absent one (null, undefined
+ * or NaN in JavaScript: all three fail every test, autoid_HK.js:201,239). */
+typedef struct sono_autoid_data {
+  double field[SONO_AUTOID_FIELDS];
+  int32_t call_type; /* index of data.callType in the host's list of call types (< 64); < 0 = absent            */
+  int32_t harmonic;  /* data.harmonic; SONO_AUTOID_ABSENT = absent                                              */
+} sono_autoid_data;
+
+/* One test of a rule on one field. */
+typedef enum sono_cond_kind {
+  SONO_COND_RANGES = 0,   /* [min, max] or [[min, max], ...]: `count` intervals from interval `first` (inRange, :200-213) */
+  SONO_COND_RELATION = 1, /* "op otherField" (:232-256): `first` = sono_relation, `count` = the other field          */
+  SONO_COND_NEVER = 2     /* a one-string condition the reference's pattern does not parse: it never holds        */
+} sono_cond_kind;
+typedef enum sono_relation { SONO_REL_EQ = 0, SONO_REL_GT = 1, SONO_REL_LT = 2, SONO_REL_GE = 3, SONO_REL_LE = 4 } sono_relation;
+typedef struct sono_autoid_cond {
+  uint32_t field, kind, first, count;
+} sono_autoid_cond;
+
+/* One entry of a species' `rules` array (autoid_HK.js:3-198 is the reference's table; it stays with the host, which
+ * flattens it into these records). */
+typedef struct sono_autoid_rule {
+  uint64_t call_type_mask;  /* bit i: call type i is listed in rule.callType; 0 = the rule has no callType         */
+  uint32_t harmonic_first;  /* rule.harmonic: `harmonic_count` values from harmonics[harmonic_first]; 0 = none     */
+  uint32_t harmonic_count;
+  uint32_t cond_first;      /* the rule's field tests                                                             */
+  uint32_t cond_count;
+  uint32_t species;         /* which species the rule belongs to                                                  */
+  uint32_t reserved;
+} sono_autoid_rule;
+
+/* autoIdHK (modules/autoid_HK.js:215-264): matched[s] = 1 when any rule of species s accepts `data`.  The host joins
+ * the names of the matched species with " / " or reports "No species matched" (:261-263). */
+int sono_autoid_match(const sono_autoid_rule* rules, uint32_t n_rules, const sono_autoid_cond* conds, const double* intervals,
+                      const int32_t* harmonics, const sono_autoid_data* data, uint8_t* matched, uint32_t n_species);
+
+/* Where a call turns, from its per-frame peak track.  The reference has no counterpart: its panel reads the knee,
+ * heel and CF markers a user drags (autoIdPanel.js:1397-1404), so these definitions are this library's own (parity
+ * unpinned).  Frames are absolute; -1 = the call has no such point.
+ *   high / low     first frame holding the highest / lowest peak bin
+ *   cf_start / end the longest run of frames whose peak stays within one bin of the peak at the call's loudest frame,
+ *                  if it spans at least 3 frames and a quarter of the call
+ *   knee           the frame where the sweep flattens most: largest |slope before| - |slope after|, slopes taken
+ *                  over max(1, frames / 8) frames; calls of fewer than 5 frames have none
+ *   heel           the frame at or after the knee where it steepens most */
+typedef struct sono_call_shape_t {
+  int64_t high_frame, low_frame, knee_frame, heel_frame, cf_start_frame, cf_end_frame;
+  int32_t knee_bin, heel_bin, cf_start_bin, cf_end_bin;
+} sono_call_shape_t;
+int sono_call_shape(const sono_frame_feature* features, uint64_t frames, uint64_t first_frame, const sono_call* call,
+                    sono_call_shape_t* out);
+
+/* The fields of runPulseId (autoIdPanel.js:1388-1462) from a call and its shape (NULL: the eight shape-derived
+ * fields stay absent): kHz = bin * sample_rate / fft_n / 1000, ms = frames * hop / sample_rate * 1000; under time
+ * expansion frequencies are multiplied and times divided (:1439-1462).  bandwidth is cfStart - endFreq when
+ * cf_call_type is set (the panel's rule for "FM-CF-FM" and "CF-FM", :1416-1421), else highest - lowest.
+ * call_type and harmonic are left absent for the host to fill. */
+int sono_autoid_data_of_call(const sono_call* call, const sono_call_shape_t* shape, uint32_t fft_n, uint32_t hop, double sample_rate,
+                             double time_expansion, int cf_call_type, sono_autoid_data* out);
+
 /* Window table exactly as the reference fills it (float32).  SONO_ERR_WINDOW for an unknown id. */
 int sono_window_table(uint32_t window_id, uint32_t fft_n, double alpha, float* out);
 /* Twiddle table in the flat stage layout: the stage with half size T occupies [T-1, 2T-1). */

@@ -14,11 +14,11 @@ const wav = require('./wav.js');
 const { Spectrogram } = require('./spectrogram_plugin.js');
 const { TileCache } = require('./tiles.js');
 
-function createBridge({ capacityBytes, maxUploadBytes = 1 << 30 } = {}) {
+function createBridge({ capacityBytes, maxUploadBytes = 1 << 30, maxPlugins = 32 } = {}) {
   const cache = new TileCache(capacityBytes);
   const recordings = new Map();   // id -> { sampleRate, length, numberOfChannels, getChannelData }
   const colormaps = new Map();    // name -> 256 x [r, g, b, a]
-  const plugins = new Map();      // option string -> Spectrogram (keeps its engines alive)
+  const plugins = new Map();      // option string -> Spectrogram (keeps its engines alive); least recently used first
 
   const body = (req) => new Promise((resolve, reject) => {
     const chunks = [];
@@ -40,11 +40,21 @@ function createBridge({ capacityBytes, maxUploadBytes = 1 << 30 } = {}) {
     if (q.has('alpha')) opts.alpha = Number(q.get('alpha'));
     const key = JSON.stringify(opts) + '|' + cmName + '|' + (colormaps.has(cmName) ? colormaps.get(cmName).version : 0);
     let p = plugins.get(key);
-    if (!p) {
+    if (p) {
+      plugins.delete(key);          // most recently used last
+    } else {
+      // every distinct option set (each step of a gain slider, say) is a plugin with GPU contexts of its own:
+      // keep the most recent `maxPlugins`; an evicted plugin's planes go first, then its contexts
+      while (plugins.size >= maxPlugins) {
+        const [oldKey, old] = plugins.entries().next().value;
+        cache.dropEngines(old._engines.values());
+        old.destroy();
+        plugins.delete(oldKey);
+      }
       opts.colorMap = colormaps.has(cmName) ? colormaps.get(cmName).table : cmName;
       p = Spectrogram.create(opts);
-      plugins.set(key, p);
     }
+    plugins.set(key, p);
     return p;
   }
 
@@ -82,7 +92,7 @@ function createBridge({ capacityBytes, maxUploadBytes = 1 << 30 } = {}) {
                              'X-Cache-Hits': String(cache.hits), 'X-Cache-Misses': String(cache.misses) });
         return res.end(Buffer.from(t.data.buffer, t.data.byteOffset, t.data.byteLength));
       }
-      if (parts[0] === 'stats') return json(res, 200, { hits: cache.hits, misses: cache.misses, bytes: cache.used, recordings: recordings.size });
+      if (parts[0] === 'stats') return json(res, 200, { hits: cache.hits, misses: cache.misses, bytes: cache.used, recordings: recordings.size, plugins: plugins.size });
       json(res, 404, { error: 'no such route' });
     } catch (e) {
       json(res, 400, { error: String((e && e.message) || e) });

@@ -22,7 +22,7 @@ const enums = {
   FRAMES_PLUGIN_STRICT: 0, FRAMES_WORKER_COMPAT: 1,
   TW_ACCURATE: 0, TW_PLUGIN_RECURRENCE: 1, TW_HOST_TABLE: 2,
   ARITH_FAST_F32: 0, ARITH_EXACT_F64: 1,
-  OUT_U8_INDEX: 0, OUT_RGBA8: 1, OUT_F32_DB: 2, OUT_F32_MAG: 3,
+  OUT_U8_INDEX: 0, OUT_RGBA8: 1, OUT_F32_DB: 2, OUT_F32_MAG: 3, OUT_FEATURES: 4,
   IN_F32: 0, IN_I16: 1,
 };
 

@@ -255,6 +255,8 @@ static napi_value js_stft(napi_env env, napi_callback_info info) {
     result = new_typed(env, napi_uint8_array, (size_t)bytes, 1, &out);
   else if (cfg.out_kind == SONO_OUT_RGBA8)
     result = new_typed(env, napi_uint8_clamped_array, (size_t)bytes, 1, &out);
+  else if (cfg.out_kind == SONO_OUT_FEATURES)   /* raw sono_frame_feature records, 8 bytes each */
+    result = new_typed(env, napi_uint8_array, (size_t)bytes, 1, &out);
   else
     result = new_typed(env, napi_float32_array, (size_t)(bytes / 4), 4, &out);
   if (!result) return NULL;
@@ -849,6 +851,154 @@ static napi_value js_stft_host_async(napi_env env, napi_callback_info info) {
     if (napi_set_named_property(env, exports, name, f_) != napi_ok) return NULL;                  \
   } while (0)
 
+/* ---- feature pass: calls, their shape, the panel's fields, the matcher -------------------- */
+
+#define CALL_NUMS 9
+static void call_to_nums(const sono_call* c, double* d) {
+  d[0] = (double)c->start_frame; d[1] = (double)c->end_frame; d[2] = (double)c->peak_frame;
+  d[3] = c->start_bin; d[4] = c->end_bin; d[5] = c->high_bin; d[6] = c->low_bin; d[7] = c->peak_bin; d[8] = c->peak_idx;
+}
+static void nums_to_call(const double* d, sono_call* c) {
+  c->start_frame = (uint64_t)d[0]; c->end_frame = (uint64_t)d[1]; c->peak_frame = (uint64_t)d[2];
+  c->start_bin = (int32_t)d[3]; c->end_bin = (int32_t)d[4]; c->high_bin = (int32_t)d[5]; c->low_bin = (int32_t)d[6];
+  c->peak_bin = (int32_t)d[7]; c->peak_idx = (uint32_t)d[8];
+}
+
+/* segmentCalls(records: Uint8Array of sono_frame_feature, threshold, minFrames, firstFrame) -> Float64Array, 9 numbers a call:
+ * startFrame, endFrame, peakFrame, startBin, endBin, highBin, lowBin, peakBin, peakIdx */
+static napi_value js_segment_calls(napi_env env, napi_callback_info info) {
+  ARGS(env, info, 4);
+  napi_typedarray_type t;
+  void* rec;
+  int64_t n = ta_data(env, argv[0], &t, &rec);
+  uint32_t thr, minf;
+  uint64_t first;
+  if (n < 0 || (n > 0 && t != napi_uint8_array) || n % 8 || !get_u32(env, argv[1], &thr) || !get_u32(env, argv[2], &minf) ||
+      !get_u64(env, argv[3], &first))
+    return throw_msg(env, "segmentCalls(records Uint8Array, threshold, minFrames, firstFrame)");
+  static sono_frame_feature none;
+  const sono_frame_feature* f = n ? (const sono_frame_feature*)rec : &none;
+  int64_t found = sono_segment_calls(f, (uint64_t)n / 8, thr, minf, first, NULL, 0);
+  if (found < 0) return throw_msg(env, "sono_segment_calls failed");
+  sono_call* calls = (sono_call*)malloc(sizeof(sono_call) * (size_t)(found ? found : 1));
+  if (!calls) return throw_msg(env, "allocation failed");
+  sono_segment_calls(f, (uint64_t)n / 8, thr, minf, first, calls, (uint64_t)found);
+  void* out = NULL;
+  napi_value result = new_typed(env, napi_float64_array, (size_t)found * CALL_NUMS, 8, &out);
+  if (result)
+    for (int64_t i = 0; i < found; i++) call_to_nums(&calls[i], (double*)out + i * CALL_NUMS);
+  free(calls);
+  return result;
+}
+
+/* callShape(records, firstFrame, call: Float64Array(9)) -> Float64Array(10): highFrame, lowFrame, kneeFrame, heelFrame,
+ * cfStartFrame, cfEndFrame, kneeBin, heelBin, cfStartBin, cfEndBin (frames -1 = none) */
+static napi_value js_call_shape(napi_env env, napi_callback_info info) {
+  ARGS(env, info, 3);
+  napi_typedarray_type t, tc;
+  void *rec, *cn;
+  int64_t n = ta_data(env, argv[0], &t, &rec), nc = ta_data(env, argv[2], &tc, &cn);
+  uint64_t first;
+  if (n <= 0 || t != napi_uint8_array || n % 8 || nc != CALL_NUMS || tc != napi_float64_array || !get_u64(env, argv[1], &first))
+    return throw_msg(env, "callShape(records Uint8Array, firstFrame, call Float64Array(9))");
+  sono_call c;
+  nums_to_call((const double*)cn, &c);
+  sono_call_shape_t s;
+  if (sono_call_shape((const sono_frame_feature*)rec, (uint64_t)n / 8, first, &c, &s) != SONO_OK)
+    return throw_msg(env, "call lies outside the feature records");
+  void* out = NULL;
+  napi_value result = new_typed(env, napi_float64_array, 10, 8, &out);
+  if (!result) return NULL;
+  double* d = (double*)out;
+  d[0] = (double)s.high_frame; d[1] = (double)s.low_frame; d[2] = (double)s.knee_frame; d[3] = (double)s.heel_frame;
+  d[4] = (double)s.cf_start_frame; d[5] = (double)s.cf_end_frame; d[6] = s.knee_bin; d[7] = s.heel_bin; d[8] = s.cf_start_bin;
+  d[9] = s.cf_end_bin;
+  return result;
+}
+
+/* autoidDataOfCall(call Float64Array(9), shape Float64Array(10) | null, fftN, hop, sampleRate, timeExpansion, cfCallType)
+ * -> Float64Array(14) in autoIdHK's field order, NaN = absent */
+static napi_value js_autoid_data_of_call(napi_env env, napi_callback_info info) {
+  ARGS(env, info, 7);
+  napi_typedarray_type tc, ts;
+  void *cn, *sn;
+  int64_t nc = ta_data(env, argv[0], &tc, &cn), ns = ta_data(env, argv[1], &ts, &sn);
+  uint32_t fft_n, hop, cf;
+  double sr, te;
+  if (nc != CALL_NUMS || tc != napi_float64_array || ns < 0 || (ns != 0 && (ns != 10 || ts != napi_float64_array)) ||
+      !get_u32(env, argv[2], &fft_n) || !get_u32(env, argv[3], &hop) || !get_f64(env, argv[4], &sr) || !get_f64(env, argv[5], &te) ||
+      !get_u32(env, argv[6], &cf))
+    return throw_msg(env, "autoidDataOfCall(call, shape | null, fftN, hop, sampleRate, timeExpansion, cfCallType)");
+  sono_call c;
+  nums_to_call((const double*)cn, &c);
+  sono_call_shape_t s;
+  if (ns) {
+    const double* d = (const double*)sn;
+    s.high_frame = (int64_t)d[0]; s.low_frame = (int64_t)d[1]; s.knee_frame = (int64_t)d[2]; s.heel_frame = (int64_t)d[3];
+    s.cf_start_frame = (int64_t)d[4]; s.cf_end_frame = (int64_t)d[5]; s.knee_bin = (int32_t)d[6]; s.heel_bin = (int32_t)d[7];
+    s.cf_start_bin = (int32_t)d[8]; s.cf_end_bin = (int32_t)d[9];
+  }
+  sono_autoid_data data;
+  if (sono_autoid_data_of_call(&c, ns ? &s : NULL, fft_n, hop, sr, te, (int)cf, &data) != SONO_OK)
+    return throw_msg(env, "bad call conversion arguments");
+  void* out = NULL;
+  napi_value result = new_typed(env, napi_float64_array, SONO_AUTOID_FIELDS, 8, &out);
+  if (result) memcpy(out, data.field, sizeof data.field);
+  return result;
+}
+
+/* autoidMatch(rules: Uint8Array of sono_autoid_rule, conds: Uint32Array (4 a test), intervals: Float64Array (2 an interval),
+ *             harmonics: Int32Array, fields: Float64Array(14), callType (index, -1 = absent), harmonic (null = absent), nSpecies)
+ * -> Uint8Array(nSpecies) */
+static napi_value js_autoid_match(napi_env env, napi_callback_info info) {
+  ARGS(env, info, 8);
+  napi_typedarray_type tr, tc, ti, th, tf;
+  void *rules, *conds, *iv, *harm, *fields;
+  int64_t nr = ta_data(env, argv[0], &tr, &rules), nc = ta_data(env, argv[1], &tc, &conds), ni = ta_data(env, argv[2], &ti, &iv);
+  int64_t nh = ta_data(env, argv[3], &th, &harm), nf = ta_data(env, argv[4], &tf, &fields);
+  double ct;
+  uint32_t nsp;
+  if (nr < 0 || nr % (int64_t)sizeof(sono_autoid_rule) || (nr && tr != napi_uint8_array) || nc < 0 || nc % 4 ||
+      (nc && tc != napi_uint32_array) || ni < 0 || ni % 2 || (ni && ti != napi_float64_array) || nh < 0 ||
+      (nh && th != napi_int32_array) || nf != SONO_AUTOID_FIELDS || tf != napi_float64_array || !get_f64(env, argv[5], &ct) ||
+      !get_u32(env, argv[7], &nsp))
+    return throw_msg(env, "autoidMatch(rules, conds, intervals, harmonics, fields, callType, harmonic, nSpecies)");
+  /* every index in the records must stay inside the arrays passed */
+  const sono_autoid_rule* r = (const sono_autoid_rule*)rules;
+  const uint32_t n_rules = (uint32_t)(nr / (int64_t)sizeof(sono_autoid_rule));
+  const sono_autoid_cond* cd = (const sono_autoid_cond*)conds;
+  for (uint32_t i = 0; i < n_rules; i++)
+    if ((uint64_t)r[i].cond_first + r[i].cond_count > (uint64_t)nc / 4 || (uint64_t)r[i].harmonic_first + r[i].harmonic_count > (uint64_t)nh)
+      return throw_msg(env, "rule record points outside its arrays");
+  for (int64_t i = 0; i < nc / 4; i++)
+    if (cd[i].kind == SONO_COND_RANGES && (uint64_t)cd[i].first + cd[i].count > (uint64_t)ni / 2)
+      return throw_msg(env, "field test points outside the intervals");
+  sono_autoid_data data;
+  memcpy(data.field, fields, sizeof data.field);
+  data.call_type = (int32_t)ct;
+  data.harmonic = SONO_AUTOID_ABSENT;
+  napi_valuetype vt;
+  double hv;
+  if (napi_typeof(env, argv[6], &vt) == napi_ok && vt == napi_number && get_f64(env, argv[6], &hv) && hv == (double)(int32_t)hv)
+    data.harmonic = (int32_t)hv;
+  void* out = NULL;
+  napi_value result = new_typed(env, napi_uint8_array, nsp, 1, &out);
+  if (!result) return NULL;
+  static uint8_t none_out[1];
+  if (sono_autoid_match(r, n_rules, cd, (const double*)iv, (const int32_t*)harm, &data, nsp ? (uint8_t*)out : none_out, nsp) != SONO_OK)
+    return throw_msg(env, "bad rule table");
+  return result;
+}
+
+static napi_value js_kernel_route(napi_env env, napi_callback_info info) {
+  ARGS(env, info, 1);
+  handle_t* h = get_handle(env, argv[0]);
+  if (!h) return NULL;
+  napi_value s;
+  NAPI_OK(env, napi_create_string_utf8(env, sono_kernel_route(h->ctx), NAPI_AUTO_LENGTH, &s));
+  return s;
+}
+
 static napi_value init(napi_env env, napi_value exports) {
   EXPORT("deviceCount", js_device_count);
   EXPORT("create", js_create);
@@ -892,6 +1042,11 @@ static napi_value init(napi_env env, napi_value exports) {
   EXPORT("wavCrop", js_wav_crop);
   EXPORT("wavAccept", js_wav_accept);
   EXPORT("pcmToDevice", js_pcm_to_device);
+  EXPORT("segmentCalls", js_segment_calls);
+  EXPORT("callShape", js_call_shape);
+  EXPORT("autoidDataOfCall", js_autoid_data_of_call);
+  EXPORT("autoidMatch", js_autoid_match);
+  EXPORT("kernelRoute", js_kernel_route);
   napi_set_named_property(env, exports, "abiVersion", make_num(env, sono_abi_version()));
   return exports;
 }

@@ -7,7 +7,10 @@
 // overlap?=0 (percent), options?}.  Message out: {type:'rendered'} -- extended, since Node has no
 // canvas to paint, with {width, height, data:Uint8ClampedArray} (RGBA, ImageData layout), whose
 // ArrayBuffer is transferred.  As in the reference, windowFunc/gainDB/rangeDB are accepted and
-// ignored; render before init is dropped.
+// ignored (spectrogramWorker.js:10-15,46,75); render before init is dropped.  Opt-in, not in the reference:
+// with options.scale === 'plugin' those three options are honoured -- the frames get the plugin's window
+// `windowFunc` (spectrogram.esm.js:105-151; an unknown name throws its error) and the quantiser becomes
+// 20*log10(2/N*|X|) with gainDB/rangeDB (:531-535); geometry, FFT and colour map stay the worker's.
 const S = require('./index.js');
 const N = S.native;
 
@@ -32,28 +35,33 @@ function makeWorkerCore(post, coreOptions) {
     lut = N.workerLut(cm);
   }
 
-  function engine(fftSize, hop) {
-    const key = fftSize + ':' + hop;
+  function engine(fftSize, hop, opts) {
+    const plugin = opts && opts.scale === 'plugin';
+    const gain = plugin && opts.gainDB != null ? +opts.gainDB : 20, range = plugin && opts.rangeDB != null ? +opts.rangeDB : 80;
+    const win = plugin ? S.windowId(opts.windowFunc) : S.WIN_WORKER_HANN;
+    const key = fftSize + ':' + hop + (plugin ? ':p' + win + ':' + opts.alpha + ':' + gain + ':' + range : '');
     let h = engines.get(key);
     if (!h) {
       const exact = arith === 'exact';
       h = N.create({
-        fftN: fftSize, hop, windowId: S.WIN_WORKER_HANN, scaleMode: S.SCALE_WORKER_LOG5, frameRule: S.FRAMES_WORKER_COMPAT,
+        fftN: fftSize, hop, windowId: win, alpha: plugin ? opts.alpha : undefined,
+        scaleMode: plugin ? S.SCALE_PLUGIN_DB : S.SCALE_WORKER_LOG5, gainDB: gain, rangeDB: range,
+        frameRule: S.FRAMES_WORKER_COMPAT,
         twiddleMode: exact ? S.TW_HOST_TABLE : S.TW_ACCURATE, arith: exact ? S.ARITH_EXACT_F64 : S.ARITH_FAST_F32,
         outKind: S.OUT_RGBA8, inKind: S.IN_F32,
       }, device);
       if (exact) {                          // this V8's Math.cos/sin, like the reference's own tables
         const tw = S.workerTwiddles(fftSize);
-        N.setTables(h, S.workerHann(fftSize), tw.cos, tw.sin);
+        N.setTables(h, plugin ? null : S.workerHann(fftSize), tw.cos, tw.sin);
       }
       engines.set(key, h);
     }
     return h;
   }
 
-  function renderSpectrogram(signal, sr, fftSize, overlapPct) {       // :38-99
+  function renderSpectrogram(signal, sr, fftSize, overlapPct, opts) { // :38-99
     const hop = N.workerHop(fftSize, overlapPct);                      // :39
-    const h = engine(fftSize, hop);
+    const h = engine(fftSize, hop, opts);
     N.setColormap(h, lut);
     const data = N.stft(h, signal);
     const g = N.geometry(h, signal.length);
@@ -78,7 +86,7 @@ function makeWorkerCore(post, coreOptions) {
       if (!canvas) return;                                             // :31
       const opts = Object.assign({}, currentOptions, d.options || {});
       if (opts.colorMap) setColorMapUint(opts.colorMap);
-      renderSpectrogram(d.buffer, d.sampleRate || sampleRate, d.fftSize || 1024, d.overlap || 0);
+      renderSpectrogram(d.buffer, d.sampleRate || sampleRate, d.fftSize || 1024, d.overlap || 0, opts);
     } else if (type === 'close') {
       for (const h of engines.values()) N.destroy(h);
       engines.clear();

@@ -96,7 +96,28 @@ server.listen(0, '127.0.0.1', async () => {
     ok(JSON.parse((await request('GET', '/stats')).body.toString()).misses === 1, 'colour map change keeps the plane');
     ok((await request('GET', '/tile/nope?width=10')).status === 404, 'unknown recording');
     ok((await request('GET', '/tile/bat1?width=10&x0=8&ncols=5')).status === 400, 'bad tile');
-    ok((await request('DELETE', '/recording/bat1')).status === 200 && server.cache.used === 0, 'delete');
+    // the same option set (frequencyMax left at 0 = Nyquist) on recordings of two rates: each gets its own Nyquist
+    const file2 = Buffer.from(file);
+    file2.writeUInt32LE(rate / 2, 12 + 12); file2.writeUInt32LE(rate, 12 + 16);          // same samples declared at half the rate
+    ok((await request('PUT', '/recording/bat2', file2)).status === 200, 'second upload');
+    const q0 = 'fftSamples=512&noverlap=256&height=100&frequencyMin=10000&colorMap=gray&width=200';
+    const b1 = { sampleRate: rate, length: n, numberOfChannels: 1, getChannelData: () => samples };
+    const b2 = Object.assign({}, b1, { sampleRate: rate / 2 });
+    const mk = () => Spectrogram.create({ fftSamples: 512, noverlap: 256, height: 100, frequencyMin: 10000, colorMap: 'gray', scale: 'linear' });
+    const p1 = mk(), p2 = mk();
+    const t1 = await request('GET', '/tile/bat1?' + q0), t2 = await request('GET', '/tile/bat2?' + q0);
+    ok(equal(new Uint8Array(t1.body), p1.renderCanvas(b1, 200).data) && equal(new Uint8Array(t2.body), p2.renderCanvas(b2, 200).data) &&
+       !equal(new Uint8Array(t1.body), new Uint8Array(t2.body)), 'frequencyMax = Nyquist of each recording');
+    p1.destroy(); p2.destroy();
+    // the plugin cache is bounded: every gain value is a plugin with GPU contexts of its own
+    const before = JSON.parse((await request('GET', '/stats')).body.toString()).plugins;
+    for (let g = 0; g < 40; g++) ok((await request('GET', '/tile/bat1?' + query + '&width=64&gainDB=' + g)).status === 200, 'gain ' + g);
+    const after = JSON.parse((await request('GET', '/stats')).body.toString()).plugins;
+    ok(before >= 1 && after === 32, 'plugin cache bounded: ' + before + ' -> ' + after);
+    const again = await request('GET', '/tile/bat1?' + query + '&width=' + W + '&x0=0&ncols=256');
+    ok(equal(new Uint8Array(again.body), columns(whole.data, W, 300, 0, 256)), 'tile after evictions');
+    ok((await request('DELETE', '/recording/bat1')).status === 200 && (await request('DELETE', '/recording/bat2')).status === 200 &&
+       server.cache.used === 0, 'delete');
     p.destroy(); pc.destroy();
   } catch (e) {
     failures++;

@@ -119,6 +119,42 @@ for (const c of cases('worker_tables')) {
      calls[0].peakBin === 180 && calls[0].highBin === 213 && calls[0].lowBin === 147, 'segmentCalls');
   const d = callToAutoIdData(calls[0], 1024, 256, 384000, { callType: 'FM' });
   ok(Math.abs(d.duration - 7 * 256 / 384) < 1e-9 && Math.abs(d.bandwidth - 66 * 0.375) < 1e-9, 'callToAutoIdData');
+  // where a call turns (the library's own definitions; same hand-made tracks as tests/test_autoid.py)
+  const { callShape } = require('./autoid.js');
+  const track = (bins) => {
+    const n = bins.length + 6, pb = new Int32Array(n).fill(50), pi = new Uint8Array(n);
+    pb.set(bins, 3); pi.fill(200, 3, 3 + bins.length);
+    return { peakBin: pb, peakIdx: pi };
+  };
+  const f1 = track([200, 190, 180, 170, 160, 150, 148, 147, 146, 146, 145, 145, 144, 144, 130, 110]);
+  f1.peakIdx[10] = 230;
+  const c1 = segmentCalls(f1, 100, 1, 500)[0], s1 = callShape(f1, c1, 500);
+  ok(s1.kneeFrame === 508 && s1.kneeBin === 150 && s1.heelFrame === 516 && s1.heelBin === 144 && s1.lowFrame === 518 &&
+     s1.cfStartFrame === 509 && s1.cfEndFrame === 512, 'callShape: FM-QCF track');
+  const d1 = callToAutoIdData(c1, 1024, 256, 384000, { callType: 'FM-QCF', shape: s1 });
+  ok(Math.abs(d1.kneeFreq - 150 * 0.375) < 1e-12 && Math.abs(d1.kneeLowTime - (508 - 518) * 256 / 384) < 1e-9 &&
+     Math.abs(d1.kneeHeelBandwidth - 6 * 0.375) < 1e-12, 'shape-derived fields');
+  const f2 = track([290, 291, 290, 290, 289, 290, 290, 291, 290, 290, 290, 290, 289, 290, 290, 290, 291, 290, 290, 290, 280, 268, 255, 240, 226]);
+  const c2 = segmentCalls(f2, 100, 1)[0], s2 = callShape(f2, c2);
+  const d2 = callToAutoIdData(c2, 1024, 256, 384000, { callType: 'CF-FM', shape: s2 });
+  ok(s2.cfStartFrame === 3 && s2.cfEndFrame === 22 && Math.abs(d2.bandwidth - 64 * 0.375) < 1e-12 &&
+     callToAutoIdData(c2, 1024, 256, 384000, { callType: 'CF-FM' }).bandwidth === undefined, 'CF part and its bandwidth rule');
+  // matcher forms the reference's table does not use
+  const rules = [
+    { name: 'ranges', rules: [{ duration: [[1, 2], [5, 6]] }] },
+    { name: 'relation', rules: [{ startFreq: ['> endFreq'], kneeFreq: ['=> heelFreq'] }] },
+    { name: 'never', rules: [{ duration: ['about 5'] }] },
+    { name: 'typed', rules: [{ callType: 'FM, QCF', harmonic: [0, 2], cfStart: [60, 70] }] },
+    { name: 'two', rules: [{ duration: [100, 200] }, { bandwidth: [3, null] }, { lowestFreq: [null, 20] }] },
+  ];
+  const m = (x) => autoIdHK(x, rules);
+  ok(m({ duration: 1.5 }) === 'ranges' && m({ duration: 3 }) === 'No species matched' &&
+     m({ startFreq: 50, endFreq: 40, kneeFreq: 45, heelFreq: 45 }) === 'relation' &&
+     m({ startFreq: 50, endFreq: 40, kneeFreq: 45 }) === 'No species matched' &&
+     m({ callType: 'QCF', harmonic: 2, cfStart: 65 }) === 'typed' && m({ callType: 'QCF', harmonic: 1, cfStart: 65 }) === 'No species matched' &&
+     m({ callType: 'FM', cfStart: 65 }) === 'No species matched' && m({ duration: 150 }) === 'two' &&
+     m({ bandwidth: 9 }) === 'No species matched' && m({ lowestFreq: 10 }) === 'two' && m({}) === 'No species matched',
+     'matcher: lists of ranges, relations, call types, harmonics, null bounds');
 }
 
 // ---------------------------------------------------------------- GPU

@@ -24,7 +24,10 @@ class TileCache {
 
   // The device-resident getFrequencies result of one channel (computed on a miss).
   plane(recId, plugin, buffer, width, channel = 0) {
-    plugin.frequencyMax = plugin.frequencyMax || buffer.sampleRate / 2;                        // :496
+    // (:496 sets frequencyMax on the plugin once; a plugin object that serves recordings of several rates must
+    // take each recording's own Nyquist when the option was left at 0)
+    if (!plugin._frequencyMaxGiven) plugin._frequencyMaxGiven = plugin.frequencyMax ? 'option' : 'nyquist';
+    if (plugin._frequencyMaxGiven === 'nyquist') plugin.frequencyMax = buffer.sampleRate / 2;
     plugin.buffer = buffer;
     const n = plugin.fftSamples;
     const hop = n - N.pluginNoverlap(n, plugin.noverlap || 0, buffer.length, width);           // :502-506
@@ -91,6 +94,18 @@ class TileCache {
       N.deviceFree(h, canvas);
     }
     return { width: ncols, height, data };
+  }
+
+  // Forget the planes that live on the given engine handles (a plugin about to be destroyed): their device
+  // memory belongs to those contexts and must be released before them.
+  dropEngines(handles) {
+    const set = new Set(handles);
+    for (const [key, pl] of this._planes) {
+      if (!set.has(pl.h)) continue;
+      this._planes.delete(key);
+      N.deviceFree(pl.h, pl.ptr);
+      this.used -= pl.nbytes;
+    }
   }
 
   // Forget one recording's planes (or all) and release their device memory.

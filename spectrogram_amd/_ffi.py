@@ -46,6 +46,17 @@ CALL_DTYPE = np.dtype([("start_frame", np.uint64), ("end_frame", np.uint64), ("p
                        ("peak_bin", np.int32), ("peak_idx", np.uint32)])
 
 
+SHAPE_DTYPE = np.dtype([("high_frame", np.int64), ("low_frame", np.int64), ("knee_frame", np.int64), ("heel_frame", np.int64),
+                        ("cf_start_frame", np.int64), ("cf_end_frame", np.int64), ("knee_bin", np.int32), ("heel_bin", np.int32),
+                        ("cf_start_bin", np.int32), ("cf_end_bin", np.int32)])
+AUTOID_RULE_DTYPE = np.dtype([("call_type_mask", np.uint64), ("harmonic_first", np.uint32), ("harmonic_count", np.uint32),
+                              ("cond_first", np.uint32), ("cond_count", np.uint32), ("species", np.uint32), ("reserved", np.uint32)])
+
+
+class AutoidData(C.Structure):
+    _fields_ = [("field", C.c_double * 14), ("call_type", C.c_int32), ("harmonic", C.c_int32)]
+
+
 class SonoWavInfo(C.Structure):
     _fields_ = [
         ("sample_rate", C.c_uint32), ("has_fmt", C.c_uint32), ("has_data", C.c_uint32), ("fmt_sample_rate", C.c_uint32),
@@ -95,6 +106,10 @@ SYMBOLS = {
     "sono_plugin_lut": (C.c_int, [_VP, _VP]),
     "sono_worker_lut": (C.c_int, [_VP, _VP]),
     "sono_segment_calls": (C.c_int64, [_VP, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint64, _VP, C.c_uint64]),
+    "sono_autoid_match": (C.c_int, [_VP, C.c_uint32, _VP, _VP, _VP, C.POINTER(AutoidData), _VP, C.c_uint32]),
+    "sono_call_shape": (C.c_int, [_VP, C.c_uint64, C.c_uint64, _VP, _VP]),
+    "sono_autoid_data_of_call": (C.c_int, [_VP, _VP, C.c_uint32, C.c_uint32, C.c_double, C.c_double, C.c_int,
+                                           C.POINTER(AutoidData)]),
     "sono_window_table": (C.c_int, [C.c_uint32, C.c_uint32, C.c_double, _VP]),
     "sono_twiddle_table": (C.c_int, [C.c_uint32, C.c_uint32, _VP, _VP]),
     "sono_create": (_VP, [C.c_int, C.POINTER(SonoConfig)]),

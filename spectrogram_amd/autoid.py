@@ -3,92 +3,153 @@
 The reference's ``autoIdHK(data)`` (modules/autoid_HK.js:215-264) matches a plain object with kHz /
 ms fields against a rule table; in the browser those numbers come from markers the user places
 (modules/autoIdPanel.js:1388-1468).  The batch engine measures them instead: the GPU emits one peak
-per frame (``SONO_OUT_FEATURES``), ``segment_calls`` groups frames into calls, and
-``call_to_autoid_data`` converts bins and frames to the reference's units with its own definitions
-(duration = (t_max - t_min) * 1000, bandwidth = high - low, autoIdPanel.js:1406-1421).
+per frame (``SONO_OUT_FEATURES``), ``segment_calls`` groups frames into calls, ``call_shape`` finds
+where a call turns, and ``call_to_autoid_data`` converts bins and frames to the reference's units
+with the panel's definitions (``sono_autoid_data_of_call``).
 
-``auto_id_hk`` restates the matcher's semantics over a rule table passed in as data (the table
-itself stays with the reference), so hosts can check that what they produce is a valid input.
+The matcher itself is one C function, ``sono_autoid_match``, shared with the Node host; this module
+only flattens a rule table (passed in as data -- the table stays with the reference) into the
+records it takes and joins the names it returns.
 """
+import ctypes as C
 import math
 import re
 
+import numpy as np
+
+from . import _ffi as F
+
 FIELDS = ["highestFreq", "lowestFreq", "kneeFreq", "heelFreq", "startFreq", "endFreq", "cfStart", "cfEnd", "duration",
           "bandwidth", "kneeLowTime", "kneeLowBandwidth", "heelLowBandwidth", "kneeHeelBandwidth"]   # autoid_HK.js:216-221
-_REL = re.compile(r"^(=|=>|>=|<|<=|>)\s*(\w+)$")                                                       # :203,233
+CF_CALL_TYPES = ("FM-CF-FM", "CF-FM")                                                                 # autoIdPanel.js:1417
+_REL = re.compile(r"^(=|=>|>=|<|<=|>)\s*(\w+)$")                                                     # autoid_HK.js:204,233
+_REL_CODE = {"=": 0, ">": 1, "<": 2, ">=": 3, "=>": 3, "<=": 4}
+_ABSENT = -2 ** 31
 
 
 def bin_to_khz(bin_index, fft_n, sample_rate):
     return bin_index * sample_rate / fft_n / 1000.0
 
 
-def call_to_autoid_data(call, fft_n, hop, sample_rate, call_type=None, harmonic=0, time_expansion=1.0):
-    """One sono_call record -> the object autoIdHK reads.  Frequencies in kHz, times in ms.
-    `time_expansion` scales like the panel does for time-expanded recordings (autoIdPanel.js:1439-1462):
-    frequencies multiply, durations divide."""
+def call_shape(features, call, first_frame=0):
+    """sono_call_shape: knee, heel, CF part, first highest / lowest frame of one call (numpy record of
+    F.SHAPE_DTYPE; frames are absolute, -1 = none).  `features` are the records from `first_frame` on."""
+    f = np.ascontiguousarray(features, F.FEATURE_DTYPE)
+    c = np.ascontiguousarray(call, F.CALL_DTYPE).reshape(1)
+    out = np.zeros(1, F.SHAPE_DTYPE)
+    rc = F.lib().sono_call_shape(F.ptr(f), len(f), int(first_frame), F.ptr(c), F.ptr(out))
+    if rc != F.OK:
+        raise F.SonoError(rc, "call lies outside the feature records")
+    return out[0]
+
+
+def call_to_autoid_data(call, fft_n, hop, sample_rate, call_type=None, harmonic=0, time_expansion=1.0, shape=None):
+    """One sono_call record (and, optionally, its shape) -> the object autoIdHK reads.  Frequencies in kHz,
+    times in ms; absent fields are left out.  `time_expansion` scales like the panel does for time-expanded
+    recordings (autoIdPanel.js:1439-1462): frequencies multiply, durations divide."""
+    c = np.ascontiguousarray(call, F.CALL_DTYPE).reshape(1)
+    sh = None if shape is None else np.ascontiguousarray(shape, F.SHAPE_DTYPE).reshape(1)
+    raw = F.AutoidData()
+    rc = F.lib().sono_autoid_data_of_call(F.ptr(c), None if sh is None else F.ptr(sh), int(fft_n), int(hop), float(sample_rate),
+                                          float(time_expansion), 1 if call_type in CF_CALL_TYPES else 0, C.byref(raw))
+    if rc != F.OK:
+        raise F.SonoError(rc, "bad call conversion arguments")
+    data = {name: raw.field[i] for i, name in enumerate(FIELDS) if not math.isnan(raw.field[i])}
     te = float(time_expansion)
-    frames = int(call["end_frame"]) - int(call["start_frame"]) + 1
-    high = bin_to_khz(int(call["high_bin"]), fft_n, sample_rate) * te
-    low = bin_to_khz(int(call["low_bin"]), fft_n, sample_rate) * te
-    data = {
-        "highestFreq": high,
-        "lowestFreq": low,
-        "startFreq": bin_to_khz(int(call["start_bin"]), fft_n, sample_rate) * te,
-        "endFreq": bin_to_khz(int(call["end_bin"]), fft_n, sample_rate) * te,
-        "peakFreq": bin_to_khz(int(call["peak_bin"]), fft_n, sample_rate) * te,
-        "duration": frames * hop / sample_rate * 1000.0 / te,
-        "bandwidth": high - low,
-        "harmonic": harmonic,
-        "startTime": int(call["start_frame"]) * hop / sample_rate * 1000.0 / te,
-    }
+    data["peakFreq"] = bin_to_khz(int(c[0]["peak_bin"]), fft_n, sample_rate) * te
+    data["startTime"] = int(c[0]["start_frame"]) * hop / sample_rate * 1000.0 / te
+    data["harmonic"] = harmonic
     if call_type is not None:
         data["callType"] = call_type
     return data
 
 
-def _is_missing(v):
-    return v is None or (isinstance(v, float) and math.isnan(v))
+def _num(v):
+    """A JavaScript value in a numeric comparison: null -> 0, undefined / non-numbers -> NaN."""
+    if v is None:
+        return 0.0
+    if isinstance(v, bool):
+        return float(v)
+    if isinstance(v, (int, float)):
+        return float(v)
+    return float("nan")
 
 
-def _in_range(val, rng):                                            # inRange, autoid_HK.js:200-213
-    if _is_missing(val):
-        return False
-    if isinstance(rng[0], (list, tuple)):
-        return any(_in_range(val, r) for r in rng)
-    lo, hi = rng[0], rng[1]
-    return lo <= val <= hi
+class RuleTable:
+    """A species rule table (the shape of autoid_HK.js:3-198) flattened for sono_autoid_match."""
+
+    def __init__(self, species_rules):
+        self.names = [sp["name"] for sp in species_rules]
+        self.call_types = []
+        rules, conds, intervals, harmonics = [], [], [], []
+        for si, sp in enumerate(species_rules):
+            for rule in sp["rules"]:
+                mask = 0
+                if rule.get("callType"):                                   # :225-228
+                    for t in (s.strip() for s in rule["callType"].split(",")):
+                        if t not in self.call_types:
+                            self.call_types.append(t)
+                        mask |= 1 << self.call_types.index(t)
+                h_first, h_count = len(harmonics), 0
+                if rule.get("harmonic"):                                   # :229
+                    harmonics.extend(int(h) for h in rule["harmonic"])
+                    h_count = len(rule["harmonic"])
+                c_first = len(conds)
+                for fi, name in enumerate(FIELDS):                         # :230-259
+                    r = rule.get(name)
+                    if not r:
+                        continue
+                    if isinstance(r[0], str) and len(r) == 1:
+                        m = _REL.match(r[0])
+                        if m and m.group(2) in FIELDS:
+                            conds.append((fi, 1, _REL_CODE[m.group(1)], FIELDS.index(m.group(2))))
+                        else:          # unknown other field: undefined fails; unparsed string: the comparison fails
+                            conds.append((fi, 2, 0, 0))
+                        continue
+                    first = len(intervals)
+                    for iv in (r if isinstance(r[0], (list, tuple)) else [r]):
+                        lo = _num(iv[0]) if len(iv) > 0 else float("nan")
+                        hi = _num(iv[1]) if len(iv) > 1 else float("nan")
+                        intervals.append((lo, hi))
+                    conds.append((fi, 0, first, len(intervals) - first))
+                rules.append((mask, h_first, h_count, c_first, len(conds) - c_first, si, 0))
+        if len(self.call_types) > 64:
+            raise ValueError("more than 64 distinct call types")
+        self._rules = np.array(rules, F.AUTOID_RULE_DTYPE) if rules else np.zeros(0, F.AUTOID_RULE_DTYPE)
+        self._conds = np.array(conds, np.uint32).reshape(-1, 4) if conds else np.zeros((0, 4), np.uint32)
+        self._intervals = np.array(intervals, np.float64).reshape(-1, 2) if intervals else np.zeros((0, 2), np.float64)
+        self._harmonics = np.array(harmonics or [0], np.int32)
+
+    def match(self, data):
+        """autoIdHK(data): names joined with ' / ', or 'No species matched' (:261-263)."""
+        data = data or {}
+        raw = F.AutoidData()
+        for i, name in enumerate(FIELDS):
+            v = data.get(name)
+            raw.field[i] = float("nan") if v is None or isinstance(v, str) else float(v)
+        ct = data.get("callType")
+        raw.call_type = self.call_types.index(ct) if ct in self.call_types else -1
+        h = data.get("harmonic")
+        ok_h = isinstance(h, (int, float)) and not isinstance(h, bool) and not (isinstance(h, float) and math.isnan(h)) \
+            and float(h) == int(h)
+        raw.harmonic = int(h) if ok_h else _ABSENT
+        matched = np.zeros(max(1, len(self.names)), np.uint8)
+        rc = F.lib().sono_autoid_match(F.ptr(self._rules), len(self._rules), F.ptr(self._conds), F.ptr(self._intervals),
+                                       F.ptr(self._harmonics), C.byref(raw), F.ptr(matched), len(self.names))
+        if rc != F.OK:
+            raise F.SonoError(rc, "bad rule table")
+        names = [n for n, m in zip(self.names, matched) if m]
+        return " / ".join(names) if names else "No species matched"
+
+
+_TABLES = {}
 
 
 def auto_id_hk(data, species_rules):
-    """autoIdHK, autoid_HK.js:215-264, over a caller-supplied rule table."""
-    data = data or {}
-
-    def rule_ok(rule):
-        if rule.get("callType"):                                     # :225-228
-            types = [s.strip() for s in rule["callType"].split(",")]
-            if data.get("callType") not in types:
-                return False
-        if rule.get("harmonic") and data.get("harmonic") not in rule["harmonic"]:   # :229
-            return False
-        for f in FIELDS:                                             # :230-259
-            r = rule.get(f)
-            if not r:
-                continue
-            if isinstance(r[0], str) and len(r) == 1:
-                m = _REL.match(r[0])
-                if m:
-                    op, ref = m.group(1), m.group(2)
-                    val, ref_val = data.get(f), data.get(ref)
-                    if _is_missing(val) or _is_missing(ref_val):
-                        return False
-                    ok = {"=": val == ref_val, ">": val > ref_val, "<": val < ref_val,
-                          ">=": val >= ref_val, "=>": val >= ref_val, "<=": val <= ref_val}[op]
-                    if not ok:
-                        return False
-                    continue
-            if not _in_range(data.get(f), r):
-                return False
-        return True
-
-    names = [sp["name"] for sp in species_rules if any(rule_ok(rule) for rule in sp["rules"])]
-    return " / ".join(names) if names else "No species matched"     # :261-263
+    """autoIdHK, autoid_HK.js:215-264, over a caller-supplied rule table (flattened once per table object)."""
+    key = id(species_rules)
+    t = _TABLES.get(key)
+    if t is None or t[0] is not species_rules:
+        t = (species_rules, RuleTable(species_rules))
+        _TABLES[key] = t
+    return t[1].match(data)

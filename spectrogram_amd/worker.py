@@ -11,7 +11,12 @@
 `height`, and (there being no 2-D context outside a browser) the painted pixels as `data`, an
 (height, width, 4) uint8 array.  The `rendered` message additionally carries width/height/data.
 As in the reference, windowFunc/gainDB/rangeDB options are accepted and ignored: the worker always
-uses its Hann window and the log10(|X|)/5 scale.
+uses its Hann window and the log10(|X|)/5 scale (spectrogramWorker.js:10-15,46,75).
+
+Opt-in, not in the reference: with ``options["scale"] == "plugin"`` those three options are honoured --
+the frames get the plugin's window ``windowFunc`` (spectrogram.esm.js:105-151; an unknown name raises its
+error) and the quantiser becomes 20*log10(2/N*|X|) with gainDB/rangeDB (:531-535); geometry, FFT and
+colour map stay the worker's.
 """
 import numpy as np
 
@@ -54,7 +59,7 @@ class SpectrogramWorker:
             if opts.get("colorMap") is not None and len(opts["colorMap"]):
                 self._set_color_map(opts["colorMap"])
             self._render(data["buffer"], data.get("sampleRate") or self._sample_rate, data.get("fftSize") or 1024,
-                         data.get("overlap") or 0)
+                         data.get("overlap") or 0, opts)
 
     def terminate(self):
         for e in self._engines.values():
@@ -77,20 +82,26 @@ class SpectrogramWorker:
             cm[len(color_map):] = [0, 0, 0, 1]
         self._lut = E.worker_lut(cm)
 
-    def _engine(self, fft_size, hop):
-        key = (fft_size, hop)
+    def _engine(self, fft_size, hop, opts=None):
+        plugin = bool(opts) and opts.get("scale") == "plugin"
+        win = E.window_id(opts.get("windowFunc")) if plugin else F.WIN_WORKER_HANN
+        gain = float(opts["gainDB"]) if plugin and opts.get("gainDB") is not None else 20.0
+        rng = float(opts["rangeDB"]) if plugin and opts.get("rangeDB") is not None else 80.0
+        alpha = (opts.get("alpha") or 0.0) if plugin else 0.0
+        key = (fft_size, hop, win, alpha, gain, rng) if plugin else (fft_size, hop)
         eng = self._engines.get(key)
         if eng is None:
-            eng = E.Engine(fft_n=fft_size, hop=hop, window_id=F.WIN_WORKER_HANN, scale_mode=F.SCALE_WORKER_LOG5,
+            eng = E.Engine(fft_n=fft_size, hop=hop, window_id=win, alpha=alpha, gain_db=gain, range_db=rng,
+                           scale_mode=F.SCALE_PLUGIN_DB if plugin else F.SCALE_WORKER_LOG5,
                            frame_rule=F.FRAMES_WORKER_COMPAT, twiddle_mode=F.TW_ACCURATE,
                            arith=F.ARITH_EXACT_F64 if self._arith == "exact" else F.ARITH_FAST_F32,
                            out_kind=F.OUT_RGBA8, device=self._device)
             self._engines[key] = eng
         return eng
 
-    def _render(self, signal, sr, fft_size, overlap_pct):            # renderSpectrogram, :38-99
+    def _render(self, signal, sr, fft_size, overlap_pct, opts=None):  # renderSpectrogram, :38-99
         hop = E.worker_hop(fft_size, overlap_pct)
-        eng = self._engine(fft_size, hop)
+        eng = self._engine(fft_size, hop, opts)
         eng.set_colormap(self._lut)
         img = eng.stft(signal)
         height, width = img.shape[0], img.shape[1]

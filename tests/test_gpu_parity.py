@@ -117,6 +117,55 @@ def test_worker_message_contract():
     w.terminate()
 
 
+def test_worker_plugin_scale_opt_in():
+    """options.scale == 'plugin' (not in the reference, off by default): the worker's frames, FFT, geometry and colour
+    map with the plugin's window `windowFunc` and its gainDB/rangeDB quantiser.  Checked against a restatement
+    assembled from the checker's parts: worker FFT (spectrogramWorker.js:206-253) of float32(x*w) with the plugin's
+    window table, then spectrogram.esm.js:195-198,531-535.  Exact arithmetic: bytes equal up to the last bit of log10
+    (at most one step, vanishingly rare); float32: within one step."""
+    x = G.signal("bat")
+    n, ov = 1024, 75
+    hop, width, frames = oracle.worker_geometry(len(x), n, ov)
+    cm = G.colormap("rainbow")
+    lut = E.worker_lut(cm)
+    for win, gain, rng in (("hamming", 0.0, 100.0), ("blackman", 40.0, 60.0)):
+        w = oracle.plugin_window(win, n)
+        idx = np.zeros((frames, n // 2), np.uint8)
+        for f in range(frames):
+            re0 = (x[f * hop:f * hop + n].astype(np.float64) * w).astype(np.float32)
+            re, im = oracle.worker_fft(re0, np.zeros(n, np.float32))
+            mag = np.sqrt(re[:n // 2].astype(np.float64) ** 2 + im[:n // 2].astype(np.float64) ** 2)
+            m = (2.0 / n * mag).astype(np.float32).astype(np.float64)
+            r = 20 * np.log10(np.maximum(m, 1e-12))
+            v = np.trunc((r + gain) / rng * 255 + 256).astype(np.int64) & 255
+            idx[f] = np.where(r < -gain - rng, 0, np.where(r > -gain, 255, v))
+        want = _image_of_indices(idx, width, lut)
+        want_idx = np.zeros((n // 2, width), np.int16)
+        want_idx[:] = idx[:width].T[::-1]
+        for f in range(width, frames):
+            want_idx[1:, 0] = idx[f][1:][::-1]
+        l4 = lut.reshape(256, 4)
+        for arith, frac in (("exact", 0.9999), ("fast", 0.99)):
+            got = []
+            wk = SpectrogramWorker(arith=arith)
+            wk.onmessage = lambda e: got.append(e["data"])
+            wk.postMessage({"type": "init", "canvas": {}, "options": {"colorMap": cm.tolist()}})
+            wk.postMessage({"type": "render", "buffer": x, "fftSize": n, "overlap": ov,
+                            "options": {"scale": "plugin", "windowFunc": win, "gainDB": gain, "rangeDB": rng}})
+            wk.terminate()
+            img = got[0]["data"]
+            assert img.shape == want.shape
+            ok = np.zeros(want_idx.shape, bool)
+            for dlt in (-1, 0, 1):
+                ok |= np.all(img == l4[(want_idx + dlt) % 256], axis=-1)
+            assert ok.all() and np.all(img == want, axis=-1).mean() >= frac, (win, arith)
+    wk = SpectrogramWorker()
+    wk.postMessage({"type": "init", "canvas": {}})
+    with pytest.raises(ValueError, match="No such window function 'nope'"):
+        wk.postMessage({"type": "render", "buffer": x, "options": {"scale": "plugin", "windowFunc": "nope"}})
+    wk.terminate()
+
+
 # ------------------------------------------------------------------ plugin path
 @pytest.mark.parametrize("case", [c for c in G.cases("plugin_get_frequencies") if c["frames"]], ids=lambda c: c["id"])
 def test_plugin_get_frequencies_exact_is_bit_identical(case):
