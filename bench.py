@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Headline benchmark: STFT Msamples/s at FFT 1024, Hann, 75 % overlap (hop 256) on MI355X.
+"""Headline benchmark: STFT Msamples/s (node) at FFT 1024, Hann, 75 % overlap (hop 256) on MI355X.
 
 Workload: one hour of synthetic 384 kHz mono bat-call PCM per GPU,
 resident in HBM before the timed region; one step = one pass of the worker-path transform
@@ -7,7 +7,12 @@ resident in HBM before the timed region; one step = one pass of the worker-path 
 RGBA ImageData layout) over the whole recording.  `--out u8` stops at the colour indices
 ([frame][bin] uint8, what the plugin's getFrequencies returns); it is reported under `variants`.  Ranks are independent (one recording each, no collective in the data path).
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--out u8|rgba] [--seconds S]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--out u8|rgba] [--seconds S] [--files F]
+
+The same line also carries (`files`) the per-file batch of BASELINE's third configuration -- 5 s x 500 kHz int16
+recordings from host memory to host memory, sharded over the ranks by `sharding.assign_files`, each rank's share
+through the overlapped `FilePipeline`, per-file checksums gathered on rank 0 -- and (`variants.node_host_*`) the
+headline workload driven through the Node.js addon (node/bench.js).
 
 Prints ONE JSON line (rank 0).  `value` is whole-job Msamples/s.  `roofline` prices the dominant
 kernel against HBM with algorithmic bytes (each input sample once + each output byte once) over
@@ -72,15 +77,34 @@ def profiled_traffic(out_name, samples):
     return best
 
 
+def profiled_counter(out_name, samples, counter):
+    """One counter of one launch of the dominant kernel from the newest profiles/*/summary.json of this workload."""
+    best = None
+    pdir = os.path.join(ROOT, "profiles")
+    for d in sorted(os.listdir(pdir)) if os.path.isdir(pdir) else []:
+        f = os.path.join(pdir, d, "summary.json")
+        if os.path.isfile(f):
+            try:
+                t = json.load(open(f))
+                if int(t.get("samples", 0)) == int(samples):
+                    best = int(t["kinds"][out_name]["per_dispatch"][counter])
+            except (ValueError, KeyError, TypeError):
+                continue
+    return best
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--out", choices=["u8", "rgba"], default="rgba")
     ap.add_argument("--seconds", type=int, default=3600, help="recording length per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-variants", action="store_true")
+    ap.add_argument("--files", type=int, default=-1,
+                    help="per-file batch: number of 5 s x 500 kHz int16 files over all ranks (-1: 400 per rank, 0: skip; "
+                         "BASELINE's configuration is 10000)")
     ap.add_argument("--rehearse", action="store_true",
                     help="multi-rank dry run on a box with one GPU: every rank uses cuda:0 and the ranks meet over gloo")
     args = ap.parse_args()
@@ -167,12 +191,63 @@ def main():
         wall = float(t.item())
     value = world * L * args.steps / wall / 1e6
 
+    # ---- per-file batch (BASELINE configs[2]): host memory -> host memory, files sharded over the ranks
+    files_res = None
+    n_files = 400 * world if args.files < 0 else args.files
+    if n_files > 0:
+        from spectrogram_amd import sharding
+        FL, FRATE = 2_500_000, 500000                       # 5 s x 500 kHz
+        rng = np.random.default_rng(7)
+        t = np.arange(FL, dtype=np.float64)
+        bufs = []
+        for b in range(4):                                   # four distinct recordings, reused
+            v = rng.standard_normal(FL) * 0.01
+            for p0 in range(10000 * (b + 1), FL - 3000, 40000):   # 5 ms pulses every 80 ms
+                tt = np.arange(2500, dtype=np.float64)
+                v[p0:p0 + 2500] += 0.3 * np.hanning(2500) * np.sin(2 * np.pi * (80e3 * tt / FRATE - 0.5 * 45e3 / 2500 * tt * tt / FRATE))
+            bufs.append(np.round(np.clip(v, -1, 1) * 32767).astype(np.int16))
+        del t
+        sizes = [FL] * n_files
+        mine = sharding.assign_files(sizes, world)[rank]
+        digest = lambda o: int(o[:: 4099].astype(np.int64).sum())          # a sparse checksum of every output
+        fkw = dict(fft_n=FFT_N, hop=HOP, window_id=F.WIN_WORKER_HANN, scale_mode=F.SCALE_WORKER_LOG5,
+                   frame_rule=F.FRAMES_WORKER_COMPAT, twiddle_mode=F.TW_ACCURATE, arith=F.ARITH_FAST_F32, in_kind=F.IN_I16,
+                   out_kind=F.OUT_RGBA8 if args.out == "rgba" else F.OUT_U8_INDEX, device=local_rank)
+        with sharding.FilePipeline(FL, slots=3, copy=False, **fkw) as pipe:
+            for _ in pipe.run([(i, bufs[i % 4]) for i in mine[:6]]):
+                pass
+            barrier()
+            t0 = time.perf_counter()
+            sums, my_s = sharding.run_file_shard(sizes, rank, world, lambda i: bufs[i % 4], pipe, digest)
+            barrier()
+            wall_f = time.perf_counter() - t0
+        if world > 1:
+            tf = torch.tensor([wall_f], dtype=torch.float64, device="cpu" if args.rehearse else dev)
+            dist.all_reduce(tf, op=dist.ReduceOp.MAX)
+            wall_f = float(tf.item())
+        gathered = sharding.gather_results((rank, len(mine), my_s, sums))
+        if rank == 0:
+            allsums = {}
+            for _, _, _, sm in gathered:
+                allsums.update(sm)
+            ref4 = [allsums[i] for i in range(min(4, n_files))]
+            files_res = {
+                "workload": "%d files x %d int16 samples (5 s x 500 kHz), host memory to host memory, worker render to %s, "
+                            "files sharded over %d rank(s) by size, 3 overlapped contexts per rank" % (
+                                n_files, FL, "RGBA8" if args.out == "rgba" else "uint8 indices", world),
+                "files": n_files, "seconds": round(wall_f, 4), "files_per_s": round(n_files / wall_f, 1),
+                "msamples_per_s": round(n_files * FL / wall_f / 1e6, 1),
+                "per_rank": [{"rank": r, "files": nf, "seconds": round(s, 4), "msamples_per_s": round(nf * FL / s / 1e6, 1) if s > 0 else None}
+                             for r, nf, s, _ in gathered],
+                "outputs_consistent": len(allsums) == n_files and all(allsums[i] == ref4[i % 4] for i in range(n_files)),
+            }
+
     result = None
     if rank == 0:
         algo_bytes = L * 4 + out_bytes
         achieved = algo_bytes / (kern_ms * 1e-3) / 1e9
         result = {
-            "metric": "STFT Msamples/s at FFT 1024 Hann 75% overlap",
+            "metric": "STFT Msamples/s (node) at FFT 1024 Hann 75% overlap; % of HBM roofline",
             "value": round(value, 1),
             "unit": "Msamples/s",
             "n_gpus": world,
@@ -198,7 +273,13 @@ def main():
                 "bytes_per_sample": round(algo_bytes / L, 3),
             },
             "checksum": checksum,
+            "notes": "host of this line: Python ctypes over the C ABI (the same C entry points the Node addon calls; "
+                     "variants.node_host_* is the same workload through node/bench.js); colour indices within 1 LSB and float32 dB "
+                     "within 0.01 dB of the reference are asserted for bins within 90 dB of the frame peak (tests/); feature "
+                     "records are bit-exact",
         }
+        if files_res:
+            result["files"] = files_res
 
     if rank == 0 and world == 1:
         # what this box's memory system delivers to the simplest possible kernels, next to the nominal 8 TB/s:
@@ -216,6 +297,20 @@ def main():
             torch.cuda.synchronize()
             result["roofline"][key] = round(nbytes * 5 / (e0.elapsed_time(e1) * 1e-3) / 1e9, 1)
         del y
+
+    if rank == 0 and world == 1:
+        # The vector-ALU roofline beside the HBM one: at hop = N/4 the transform is ~200 flop per sample over 6-12
+        # bytes, i.e. at or above the machine balance, so instruction issue -- not bytes -- fills most of the time.
+        # insts_per_launch: SQ_INSTS_VALU of one launch from the committed counter profile of this workload;
+        # issue_peak_measured: this GPU's v_fma_f32 issue rate at the kernels' occupancy, measured now.
+        probe = make_engine(OUT_KINDS[args.out])
+        peak = probe.measure_valu_peak()
+        probe.close()
+        insts = profiled_counter(args.out, L, "SQ_INSTS_VALU")
+        result["roofline"]["valu"] = {
+            "insts_per_launch": insts, "issue_peak_measured": round(peak, 1), "unit": "G wavefront-instructions/s",
+            "frac": round(insts / (kern_ms * 1e-3) / 1e9 / peak, 4) if insts and peak > 0 else None,
+        }
 
     if rank == 0 and world == 1 and not args.no_variants:
         # other entry points of the same path on the same recording (not the headline; same timing method)
@@ -244,6 +339,21 @@ def main():
             w2, k2, ob2, _, _ = run(o, k, 1, **sp)
             result["variants"][name] = {"value": round(n_in * k / w2 / 1e6, 1), "kernel_ms": round(k2, 4),
                                         "roofline_frac": round((n_in * 4 + ob2) / (k2 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+        # the headline workload through the JavaScript host (N-API addon): must agree with the figure above
+        import shutil
+        import subprocess
+        node = shutil.which("node")
+        if node and os.path.isfile(os.path.join(ROOT, "node", "build", "sonospec.node")):
+            try:
+                r = subprocess.run([node, os.path.join(ROOT, "node", "bench.js"), "--seconds", str(args.seconds), "--steps",
+                                    str(args.steps), "--warmup", str(args.warmup), "--out", args.out],
+                                   capture_output=True, text=True, timeout=600)
+                j = json.loads(r.stdout.strip().splitlines()[-1]) if r.returncode == 0 else {"error": r.stderr[-300:]}
+            except (subprocess.SubprocessError, ValueError, IndexError) as e:
+                j = {"error": str(e)[:300]}
+            if "value" in j:
+                j["vs_python_host"] = round(j["value"] / value, 4)
+            result["variants"]["node_host_%s_1024" % args.out] = j
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         import shutil
@@ -292,6 +402,15 @@ def main():
                     "seconds": round(j["wall_s"], 2),
                     "c_port": c_port,
                 }
+                # how the restatement relates to the reference itself (which cannot travel to this box): both were
+                # timed in the build container on one thread and the same 10 s signal by tools/time_reference.js
+                rf = os.path.join(ROOT, "profiles", "cpu_baseline_ratio.json")
+                if os.path.isfile(rf):
+                    ratio = json.load(open(rf))
+                    result["cpu_baseline"]["restatement_over_reference"] = ratio["restatement_over_reference"]
+                    result["cpu_baseline"]["reference_equivalent"] = round(j["msamples_per_s"] / ratio["restatement_over_reference"], 2)
+                    result["cpu_baseline"]["ratio_measured"] = "%s, %s: reference %.2f, restatement %.2f Msamples/s" % (
+                        ratio["node"], ratio["signal"], ratio["reference_msamples_per_s"], ratio["restatement_msamples_per_s"])
 
     if world > 1:
         dist.barrier()

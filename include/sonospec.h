@@ -464,6 +464,11 @@ int sono_pcm_to_f32(sono_ctx* ctx, const void* src, int mem, uint32_t format_tag
 
 /* ---- timing (HIP events on the context's stream) ------------------------------------------ */
 
+/* What this GPU's vector ALU issues at the transform kernels' occupancy (sixteen wavefronts per CU of independent
+ * v_fma_f32), in 10^9 wavefront-instructions per second; < 0 on error.  A benchmark host prices the kernels'
+ * instruction counts against it beside the HBM roofline.  Takes a few milliseconds; allocates and waits. */
+double sono_measure_valu_peak(sono_ctx* ctx);
+
 int sono_timer_start(sono_ctx* ctx);
 /* Records the stop event, waits for it and returns the elapsed milliseconds (< 0 on error). */
 double sono_timer_stop_ms(sono_ctx* ctx);

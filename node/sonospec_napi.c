@@ -990,6 +990,13 @@ static napi_value js_autoid_match(napi_env env, napi_callback_info info) {
   return result;
 }
 
+static napi_value js_measure_valu_peak(napi_env env, napi_callback_info info) {
+  ARGS(env, info, 1);
+  handle_t* h = get_handle(env, argv[0]);
+  if (!h) return NULL;
+  return make_num(env, sono_measure_valu_peak(h->ctx));
+}
+
 static napi_value js_kernel_route(napi_env env, napi_callback_info info) {
   ARGS(env, info, 1);
   handle_t* h = get_handle(env, argv[0]);
@@ -1047,6 +1054,7 @@ static napi_value init(napi_env env, napi_value exports) {
   EXPORT("autoidDataOfCall", js_autoid_data_of_call);
   EXPORT("autoidMatch", js_autoid_match);
   EXPORT("kernelRoute", js_kernel_route);
+  EXPORT("measureValuPeak", js_measure_valu_peak);
   napi_set_named_property(env, exports, "abiVersion", make_num(env, sono_abi_version()));
   return exports;
 }

@@ -142,6 +142,7 @@ SYMBOLS = {
     "sono_device_free": (C.c_int, [_VP, _VP]),
     "sono_copy_to_device": (C.c_int, [_VP, _VP, _VP, C.c_uint64]),
     "sono_copy_to_host": (C.c_int, [_VP, _VP, _VP, C.c_uint64]),
+    "sono_measure_valu_peak": (C.c_double, [_VP]),
     "sono_timer_start": (C.c_int, [_VP]),
     "sono_timer_stop_ms": (C.c_double, [_VP]),
 }

@@ -876,6 +876,26 @@ int sono_copy_to_host(sono_ctx* c, void* dst, const void* src, uint64_t bytes) {
   return sono_wait(c);
 }
 
+double sono_measure_valu_peak(sono_ctx* c) {
+  if (!c) return -1.0;
+  if (hipSetDevice(c->device) != hipSuccess) return -1.0;
+  float* sink = nullptr;
+  if (hipMalloc((void**)&sink, 256) != hipSuccess) return -1.0;
+  double best = -1.0;
+  for (int rep = 0; rep < 3; ++rep) {  // the first launch also loads the code
+    if (hipEventRecord(c->ev_start, c->stream) != hipSuccess) break;
+    const uint64_t n = launch_valu_peak(sink, 20000, c->stream);
+    float ms = 0;
+    if (hipEventRecord(c->ev_stop, c->stream) != hipSuccess || hipEventSynchronize(c->ev_stop) != hipSuccess ||
+        hipEventElapsedTime(&ms, c->ev_start, c->ev_stop) != hipSuccess || !(ms > 0))
+      break;
+    const double rate = (double)n / ((double)ms * 1e-3) / 1e9;
+    if (rate > best) best = rate;
+  }
+  (void)hipFree(sink);
+  return best;
+}
+
 int sono_timer_start(sono_ctx* c) {
   if (!c) return SONO_ERR_ARG;
   HIP_TRY(c, hipSetDevice(c->device));

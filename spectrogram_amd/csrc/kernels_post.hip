@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include "sono_internal.h"
+#include "sono_launch.h"
 
 namespace sono {
 
@@ -336,6 +337,36 @@ int launch_pcm_to_f32(const void* src, uint32_t format_tag, uint32_t bits, uint3
   else if (format_tag == 1 && bits == 32) hipLaunchKernelGGL(pcm_to_f32_kernel<3>, grid, block, 0, stream, s, channels, channel, frames, dst);
   else return SONO_ERR_ARG;
   return hipGetLastError() == hipSuccess ? SONO_OK : SONO_ERR_DEVICE;
+}
+
+// ------------------------------------------------------------------------------------------
+// What the vector ALU of this GPU issues when nothing else is in the way: sixteen wavefronts per CU (the
+// transform kernels' occupancy), each a long run of independent v_fma_f32.  The STFT kernels are priced
+// against this number next to the HBM roofline, because at hop = N/4 their arithmetic, not their bytes,
+// is what fills the time.
+constexpr int kPeakChains = 16, kPeakUnroll = 8;
+__global__ __launch_bounds__(1024) void valu_peak_kernel(float* __restrict__ sink, uint32_t iterations, float a, float b) {
+  float v[kPeakChains];
+#pragma unroll
+  for (int i = 0; i < kPeakChains; ++i) v[i] = (float)(threadIdx.x + i);
+  for (uint32_t it = 0; it < iterations; ++it) {
+#pragma unroll
+    for (int u = 0; u < kPeakUnroll; ++u)
+#pragma unroll
+      for (int i = 0; i < kPeakChains; ++i) v[i] = __builtin_fmaf(v[i], a, b);
+  }
+  float s = 0;
+#pragma unroll
+  for (int i = 0; i < kPeakChains; ++i) s += v[i];
+  if (s == 12345.678f) sink[0] = s;  // keeps the chains alive; never true for the a, b the host passes
+}
+
+// Enqueues the probe; returns the number of wavefront-level v_fma_f32 it issues.
+uint64_t launch_valu_peak(float* sink, uint32_t iterations, void* stream_v) {
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_v);
+  const int cus = device_cu_count();
+  hipLaunchKernelGGL(valu_peak_kernel, dim3(cus), dim3(1024), 0, stream, sink, iterations, 0.999f, 0.001f);
+  return (uint64_t)cus * 16 * iterations * kPeakUnroll * kPeakChains;
 }
 
 }  // namespace sono

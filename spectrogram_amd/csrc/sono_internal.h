@@ -99,6 +99,7 @@ bool fast_features_available(const StftParams& p);
 uint64_t fast_rgba_scratch_bytes();
 int launch_pcm_to_f32(const void* src, uint32_t format_tag, uint32_t bits, uint32_t channels, uint32_t channel, uint64_t frames,
                       float* dst, void* hip_stream);
+uint64_t launch_valu_peak(float* sink, uint32_t iterations, void* hip_stream);
 int launch_frame_peaks(const uint8_t* idx, uint64_t frames, uint32_t bins, int32_t* peak_bin, uint8_t* peak_idx,
                        void* hip_stream);
 

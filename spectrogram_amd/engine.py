@@ -251,6 +251,10 @@ class Engine:
         self._check(self._lib.sono_frame_peaks(self._ctx, F.ptr(idx), Fr, B, F.ptr(pb), F.ptr(pv), F.MEM_HOST))
         return pb, pv
 
+    def measure_valu_peak(self):
+        """10^9 wavefront-level v_fma_f32 per second this GPU issues at 16 wavefronts per CU (sono_measure_valu_peak)."""
+        return float(self._lib.sono_measure_valu_peak(self._ctx))
+
     # -- timing with HIP events on the context's stream
     def timer_start(self):
         self._check(self._lib.sono_timer_start(self._ctx))

@@ -88,6 +88,21 @@ def merge_calls(call_lists, min_frames=1):
     return out
 
 
+def run_file_shard(sizes, rank, world_size, load, pipeline, digest):
+    """The per-file batch on one rank (the reference loads one file after the other, modules/fileLoader.js:110-157):
+    this rank's share of the files (`assign_files` over `sizes`) goes through `pipeline` -- a FilePipeline, or anything
+    with run(iterable of (tag, samples)) -> iterable of (tag, output) -- in ascending file order.
+    `load(i)` returns file i's samples, `digest(output)` what to keep of its result (the outputs themselves stay on
+    the rank that made them).  Returns ({file index: digest}, seconds); rank 0 collects the dicts with gather_results."""
+    import time
+    mine = assign_files(sizes, world_size)[rank]
+    t0 = time.perf_counter()
+    kept = {}
+    for i, out in pipeline.run((i, load(i)) for i in mine):
+        kept[i] = digest(out)
+    return kept, time.perf_counter() - t0
+
+
 def gather_results(local, dst=0):
     """Host-side gather of arbitrary per-rank results on rank `dst` (list indexed by rank, else None)."""
     import torch.distributed as dist

@@ -152,3 +152,60 @@ def test_world_size_2_gloo_gather_matches_single_process():
     ft["peak_bin"] = oracle.frame_peaks_f32(mags)
     ft["peak_idx"] = whole_idx[np.arange(len(whole_idx)), ft["peak_bin"]]
     assert sharding.merge_calls([g[2] for g in gathered]).tobytes() == E.segment_calls(ft, 150, 1).tobytes()
+
+
+def _batch_rank_main(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import zlib
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    files, sizes = _batch_files()
+
+    class CheckerPipeline:        # the CPU checker stands in for the GPU pipeline: this test is about the orchestration
+        def run(self, items):
+            for tag, x in items:
+                yield tag, oracle.worker_render(x, 1024, 75.0, None)
+
+    kept, secs = sharding.run_file_shard(sizes, rank, world, lambda i: files[i], CheckerPipeline(),
+                                         lambda img: zlib.crc32(img.tobytes()))
+    gathered = sharding.gather_results((rank, kept, secs))
+    dist.barrier()
+    if rank == 0:
+        q.put(gathered)
+    dist.destroy_process_group()
+
+
+def _batch_files():
+    rng = np.random.default_rng(99)
+    sizes = [1024 + 256 * int(k) for k in rng.integers(4, 60, 11)]
+    files = [(rng.standard_normal(n) * 0.2).astype(np.float32) for n in sizes]
+    return files, sizes
+
+
+def test_world_size_2_file_batch_orchestration():
+    """run_file_shard + gather_results over two gloo ranks: every file is transformed exactly once, on the rank
+    assign_files gave it to, and the gathered digests equal a single process's."""
+    import zlib
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_batch_rank_main, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    gathered = q.get(timeout=240)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    files, sizes = _batch_files()
+    parts = sharding.assign_files(sizes, 2)
+    assert [r for r, _, _ in gathered] == [0, 1]
+    merged = {}
+    for r, kept, secs in gathered:
+        assert sorted(kept) == parts[r] and secs > 0
+        merged.update(kept)
+    assert sorted(merged) == list(range(len(files)))
+    for i, x in enumerate(files):
+        assert merged[i] == zlib.crc32(oracle.worker_render(x, 1024, 75.0, None).tobytes())
