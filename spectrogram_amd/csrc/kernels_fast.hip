@@ -24,9 +24,11 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <cstdlib>
 #include <vector>
 
 #include "sono_device.h"
+#include "sono_fft32.h"
 #include "sono_internal.h"
 #include "sono_launch.h"
 #include "sono_rgba_flush.h"
@@ -57,117 +59,6 @@ constexpr int kTileFrames = kRoundFrames / 16;     // frames per wavefront and r
 using rgba_flush::kRoundBytes;
 using rgba_flush::kLutBytes;
 static_assert(kRoundFrames == kMaxWaves * kTileFrames, "a round is one tile per wavefront");
-
-// cos/sin(2*pi*j/32), j = 0..15
-__device__ constexpr float kC32[16] = {1.0f,          0.98078528040323044913f, 0.92387953251128675613f, 0.83146961230254523708f,
-                                       0.70710678118654752440f, 0.55557023301960222474f, 0.38268343236508977173f, 0.19509032201612826785f,
-                                       0.0f,          -0.19509032201612826785f, -0.38268343236508977173f, -0.55557023301960222474f,
-                                       -0.70710678118654752440f, -0.83146961230254523708f, -0.92387953251128675613f, -0.98078528040323044913f};
-__device__ constexpr float kS32[16] = {0.0f,          0.19509032201612826785f, 0.38268343236508977173f, 0.55557023301960222474f,
-                                       0.70710678118654752440f, 0.83146961230254523708f, 0.92387953251128675613f, 0.98078528040323044913f,
-                                       1.0f,          0.98078528040323044913f, 0.92387953251128675613f, 0.83146961230254523708f,
-                                       0.70710678118654752440f, 0.55557023301960222474f, 0.38268343236508977173f, 0.19509032201612826785f};
-
-__host__ __device__ constexpr int brev5(int v) {
-  return ((v & 1) << 4) | ((v & 2) << 2) | (v & 4) | ((v & 8) >> 2) | ((v & 16) >> 4);
-}
-
-// In-register 32-point forward DFT, radix-2 decimation in time.  Input in bit-reversed register
-// order, output in natural order.  All indices fold to constants after unrolling.
-__device__ __forceinline__ void fft32(float (&re)[32], float (&im)[32]) {
-#pragma unroll
-  for (int s = 0; s < 5; ++s) {
-    const int half = 1 << s;
-#pragma unroll
-    for (int g = 0; g < 32; g += 2 * half) {
-#pragma unroll
-      for (int j = 0; j < half; ++j) {
-        const int t = j * (16 >> s);  // twiddle W_32^t = (C, -S)
-        const int i0 = g + j, i1 = i0 + half;
-        const float ar = re[i0], ai = im[i0], br = re[i1], bi = im[i1];
-        if (t == 0) {
-          re[i0] = ar + br; im[i0] = ai + bi;
-          re[i1] = ar - br; im[i1] = ai - bi;
-        } else if (t == 8) {  // w = -i
-          re[i0] = ar + bi; im[i0] = ai - br;
-          re[i1] = ar - bi; im[i1] = ai + br;
-        } else {
-          const float C = kC32[t], S = kS32[t];
-          const float o1r = __builtin_fmaf(S, bi, __builtin_fmaf(C, br, ar));
-          const float o1i = __builtin_fmaf(-S, br, __builtin_fmaf(C, bi, ai));
-          re[i0] = o1r; im[i0] = o1i;
-          re[i1] = __builtin_fmaf(2.0f, ar, -o1r);
-          im[i1] = __builtin_fmaf(2.0f, ai, -o1i);
-        }
-      }
-    }
-  }
-}
-
-// The same 32-point network with twiddles from a table (the plugin's recurrence factors or a host
-// table: not exact roots of unity, so every butterfly must use the very factor the reference uses).
-// tw(half, j) returns the factor (cos, sin) of the butterfly at position j of a stage with half size
-// `half` (sin < 0 for the forward transform, spectrogram.esm.js:176-190).  FIRST: these are the first
-// five stages of the 1024-point transform, where j == 0 is the factor (1, 0) exactly in every table
-// this kernel accepts (checked on the host); in the last five stages every butterfly has a factor.
-template <bool FIRST, class TwFn>
-__device__ __forceinline__ void fft32_table(float (&re)[32], float (&im)[32], TwFn tw) {
-#pragma unroll
-  for (int s = 0; s < 5; ++s) {
-    const int half = 1 << s;
-#pragma unroll
-    for (int j = 0; j < half; ++j) {
-      float2 w = make_float2(1.0f, 0.0f);
-      if (!FIRST || j != 0) w = tw(half, j);
-#pragma unroll
-      for (int g = 0; g < 32; g += 2 * half) {
-        const int i0 = g + j, i1 = i0 + half;
-        const float ar = re[i0], ai = im[i0], br = re[i1], bi = im[i1];
-        if (FIRST && j == 0) {
-          re[i0] = ar + br; im[i0] = ai + bi;
-          re[i1] = ar - br; im[i1] = ai - bi;
-        } else {  // o1 = a + w*b, o2 = a - w*b = 2a - o1
-          const float o1r = __builtin_fmaf(-w.y, bi, __builtin_fmaf(w.x, br, ar));
-          const float o1i = __builtin_fmaf(w.y, br, __builtin_fmaf(w.x, bi, ai));
-          re[i0] = o1r; im[i0] = o1i;
-          re[i1] = __builtin_fmaf(2.0f, ar, -o1r);
-          im[i1] = __builtin_fmaf(2.0f, ai, -o1i);
-        }
-      }
-    }
-  }
-}
-
-// Orders this wavefront's LDS traffic for the compiler.  The hardware executes one wavefront's LDS
-// instructions in issue order, so data written by one lane is visible to a later read by another
-// lane of the same wavefront without a workgroup barrier.
-__device__ __forceinline__ void wave_sync() {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
-template <typename In>
-__device__ __forceinline__ float ld(const In* p, int i);
-template <>
-__device__ __forceinline__ float ld<float>(const float* p, int i) {
-  return p[i];
-}
-template <>
-__device__ __forceinline__ float ld<int16_t>(const int16_t* p, int i) {
-  return (float)p[i] * (1.0f / 32768.0f);
-}
-
-// quantise |X|^2 (already including the pair-separation factor through fs.b) to a byte of `acc`
-template <bool PLUGIN, int BYTE>
-__device__ __forceinline__ uint32_t put_index(float msq, const FastScale& fs, uint32_t acc) {
-  if constexpr (PLUGIN) {
-    return fast_plugin_byte<BYTE>(msq, fs, acc);
-  } else {
-    const float t = __builtin_floorf(__builtin_fmaf(__log2f(msq), fs.a, fs.b));
-    return __builtin_amdgcn_cvt_pk_u8_f32(t, BYTE, acc);  // saturates to [0,255]; NaN -> 0
-  }
-}
 
 // HOP32 > 0: hop == 32*HOP32, so frame B's sample 32a+l is frame A's sample 32(a+HOP32)+l and one
 // run of 32+HOP32 loads feeds both frames.  HOP32 == 0: any hop, two runs of 32 loads.
@@ -595,7 +486,12 @@ int launch_stft_fast(const StftParams& p, void* stream_v) {
   const bool rgba = p.out_kind == SONO_OUT_RGBA8, feat = p.out_kind == SONO_OUT_FEATURES;
   const bool flt = p.out_kind == SONO_OUT_F32_DB || p.out_kind == SONO_OUT_F32_MAG;
   if (rgba) {
-    if (!fast_rgba_available(p) || !p.tile_scratch) return 1;
+    if (!fast_rgba_available(p)) return 1;
+    // the image writer that keeps its exchange in LDS (kernels_fast_rgba.hip); SONO_RGBA_GLOBAL_SLOTS=1 selects the
+    // older one below, which parks the indices in a global scratch buffer (kept for comparison runs)
+    static const bool global_slots = getenv("SONO_RGBA_GLOBAL_SLOTS") != nullptr;
+    if (!global_slots) return launch_stft_fast_rgba(p, stream_v);
+    if (!p.tile_scratch) return 1;
   } else if (flt) {
     if (!fast_float_available(p)) return 1;
     if (p.fast_mode == 2 && !p.pair_exact) return 1;  // two frames per transform: see StftParams::pair_exact

@@ -61,6 +61,8 @@ int launch_stft_general(const StftParams& p, bool exact_f64, void* hip_stream);
 // kernels_fast.hip: float32 kernels with accurate twiddles (returns 1 if this size/mode has no fast kernel).
 int launch_stft_fast(const StftParams& p, void* hip_stream);
 void build_fast_table_1024(std::vector<float>& t);
+// kernels_fast_rgba.hip: the 1024-point kernel that writes the RGBA image itself, colour-index exchange in LDS.
+int launch_stft_fast_rgba(const StftParams& p, void* hip_stream);
 // kernels_fast512.hip: float32 kernel for 512-point frames with exact roots of unity (fast_mode 1, fast_table from
 // build_fast_table_512); colour indices and per-frame peaks.  Returns 1 if it does not serve this launch.
 int launch_stft_fast512(const StftParams& p, void* hip_stream);

@@ -388,7 +388,7 @@ def test_kernel_route_is_visible_and_default_view_is_fast():
         assert eng.kernel_route() == ""
         eng.set_colormap(lut)
         img = eng.stft(x)
-        assert eng.kernel_route() == "stft1024_u8_kernel<table>:rgba"
+        assert eng.kernel_route() == "stft1024_rgba_kernel<table>:rgba"
     want = ref[:, lo:hi].T[::-1].astype(np.int16)
     l4 = lut.reshape(256, 4)
     ok = np.zeros(want.shape, bool)
@@ -400,7 +400,7 @@ def test_kernel_route_is_visible_and_default_view_is_fast():
     # specialised kernel, exact arithmetic
     with worker_engine(1024, 256, F.ARITH_FAST_F32) as eng:
         eng.stft(x)
-        assert eng.kernel_route() == "stft1024_u8_kernel<roots>:rgba + stft_general_kernel<float>"   # + the wrapped last frame
+        assert eng.kernel_route() == "stft1024_rgba_kernel<roots>:rgba + stft_general_kernel<float>"   # + the wrapped last frame
     with plugin_engine(4096, 256, F.ARITH_FAST_F32, out_kind=F.OUT_RGBA8, bin_lo=160, bin_hi=1280) as eng:
         eng.stft(x)
         assert eng.kernel_route() == "stft_mw_kernel<4096>:u8 + colorize_kernel"
