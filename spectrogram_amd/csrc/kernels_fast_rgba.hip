@@ -4,8 +4,8 @@
 // A frame is one image COLUMN and image rows are tens of megabytes apart, so frames cannot be stored as they are
 // finished: a workgroup collects the colour indices of a round of 128 consecutive frames (8 per wavefront, two
 // iterations of 4) and then every wavefront writes 32 image rows of the round as 512-byte runs.  That exchange is
-// a transpose between "wavefront w holds frames 8w..8w+7, all bins" and "wavefront w writes bins 32w..32w+31, all
-// 128 frames": 64 KiB per round.  Passing it through a global scratch buffer costs a quarter of everything the
+// a transpose between "wavefront w holds frames 4w..4w+3 and 64+4w..64+4w+3, all bins" and "wavefront w writes bins
+// 32w..32w+31, all 128 frames": 64 KiB per round.  Passing it through a global scratch buffer costs a quarter of everything the
 // memory fabric moves for this kernel (the lines are evicted from L2 between their write and their read), so it
 // lives in LDS here, and the rest of the kernel is arranged to leave room for it:
 //   * the 32 x 32 transposes between the two register passes are split: register bit 4 <-> lane bit 4 by
@@ -43,9 +43,15 @@ constexpr int kLutBytes = 1024;
 constexpr int kBlkPitch = 20;                        // floats per row of a 16 x 16 transpose block
 constexpr int kBlkFloats = 16 * kBlkPitch;
 constexpr int kWaveBytes = 4 * kBlkFloats * 4;       // 5120: four 16-lane rows
-constexpr int kQuarterBytes = kWaveBytes / 2;        // epilogue, per transform: Z[k] at [0, 1024), Z[N-k] at [1024, 1024 + 129*8)
-constexpr int kMirrorOffset = 128 * 8;
-static_assert(kMirrorOffset + 129 * 8 <= kQuarterBytes, "an epilogue quarter must fit half the wavefront's slice");
+constexpr int kQuarterBytes = kWaveBytes / 2;        // epilogue, per transform: 128 values Z[k], then 128 partners Z[N-k]
+// 128 complex values laid out for the epilogue: value j (8 bytes) of a quarter sits in plane (j >> 1) & 1 at
+// 16 * (j >> 2) + 8 * (j & 1), so that a lane's four consecutive values are one 16-byte read per plane at 16 * lane
+// (conflict-free), and the second plane starts 16 banks after the first so that the 8-byte stores of 16 consecutive
+// lanes cover 32 different banks.
+constexpr int kPlane1 = 512 + 64;
+constexpr int kMirrorOffset = kPlane1 + 512;
+static_assert(2 * kMirrorOffset <= kQuarterBytes, "an epilogue quarter must fit half the wavefront's slice");
+__device__ __forceinline__ int quarter_pos(int j) { return ((j >> 1) & 1) * kPlane1 + (j >> 2) * 16 + (j & 1) * 8; }
 constexpr int kSlotPitch = 130;                      // 16-byte cells per frame group: 128 bin quads + 2 (bank spread of the read-out)
 constexpr int kSlotBytes = 32 * kSlotPitch * 16;
 constexpr int kOffWin = kTwBytes, kOffLut = kOffWin + kWinBytes, kOffWave = kOffLut + kLutBytes, kOffSlot = kOffWave + kWaves * kWaveBytes;
@@ -153,8 +159,7 @@ __global__ __launch_bounds__(kWaves * 64, 4) void stft1024_rgba_kernel(StftParam
   unsigned char* wbuf = smem + kOffWave + wave * kWaveBytes;
   float* blk = reinterpret_cast<float*>(wbuf) + (lane >> 4) * kBlkFloats;
   const int ll = lane & 15;
-  float2* lbuf = reinterpret_cast<float2*>(wbuf + h * kQuarterBytes);
-  float2* mbuf = reinterpret_cast<float2*>(wbuf + h * kQuarterBytes + kMirrorOffset);
+  unsigned char* qbuf = wbuf + h * kQuarterBytes;
   const float4* win_row = reinterpret_cast<const float4*>(win_lds + l * kWinPitch);
 
   const In* __restrict__ x = reinterpret_cast<const In*>(p.pcm);
@@ -175,8 +180,10 @@ __global__ __launch_bounds__(kWaves * 64, 4) void stft1024_rgba_kernel(StftParam
   // input; an odd last frame is computed as the second member of the pair before it (shifted).
   auto locate = [&](uint64_t it) -> Unit {
     Unit u;
-    const uint64_t tile_id = ((it / kTileIters) * gridDim.x + vb) * kWaves + wave;
-    const uint64_t pair0 = (tile_id * kTileIters + it % kTileIters) * 2;
+    // frame group (4 frames) 16 * sub + wave of the round: the 16 wavefronts of an iteration read one contiguous span
+    // of samples, so the 3/4 overlap between neighbouring groups is re-read while it is still in cache
+    const uint64_t group = (((it / kTileIters) * gridDim.x + vb) * kTileIters + it % kTileIters) * kWaves + wave;
+    const uint64_t pair0 = group * 2;
     u.active = pair0 < npairs;  // wave-uniform
     if (!u.active) {            // nothing left: point at frame 0 so that the sample loads stay in bounds
       u.f0 = 0;
@@ -284,27 +291,32 @@ __global__ __launch_bounds__(kWaves * 64, 4) void stft1024_rgba_kernel(StftParam
       }
 
       // Epilogue in quarters of 128 bins.  For quarter Q the registers k2 = 4Q + r hold Z[k] for k = 128Q + 32r + l and
-      // the registers 28 - 4Q + r hold the partners Z[N - k]; both go to LDS ascending in k (lbuf[k - 128Q],
-      // mbuf[k - 128Q]) so that four consecutive bins are two aligned 16-byte reads each.  Lane 0's partner registers
-      // sit one row off, so it also supplies mbuf[0] = Z[N - 128Q].
+      // the registers 28 - 4Q + r hold the partners Z[N - k]; both go to LDS as value k - 128Q of their half of the
+      // quarter buffer, so that a lane's four consecutive bins are two 16-byte reads each.  Lane 0's partner registers
+      // sit one row off: its partner of value 0 is Z[N - 128Q], register (32 - 4Q) mod 32.
       const bool shifted = cur.shifted;
       int lq = l;
+      asm volatile("" : "+v"(lq));
+      unsigned char* zw = qbuf + quarter_pos(lq);                          // value 32r + l: + 128r
+      unsigned char* pw = qbuf + kMirrorOffset + quarter_pos(32 - lq);     // partner 32(3-r) + 32 - l: + 128(3-r)
+      // lane 0's partner of row 0 would be value 128, which nobody reads: it stores value 0 there instead
+      unsigned char* pw0 = lq == 0 ? qbuf + kMirrorOffset : pw + 128 * 3;
+      const unsigned char* zr = qbuf + 16 * lq;
       uint32_t wa2[2], wb2[2];
 #pragma unroll
       for (int Q = 0; Q < 4; ++Q) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int kl = 4 * Q + r, km = 28 - 4 * Q + r;
-          lbuf[32 * r + l] = make_float2(re[kl], im[kl]);
-          mbuf[32 * (3 - r) + 32 - l] = make_float2(re[km], im[km]);
+          const int kl = 4 * Q + r, km = 28 - 4 * Q + r, k0 = (32 - 4 * Q) & 31;
+          *reinterpret_cast<float2*>(zw + 128 * r) = make_float2(re[kl], im[kl]);
+          if (r == 0) *reinterpret_cast<float2*>(pw0) = lq == 0 ? make_float2(re[k0], im[k0]) : make_float2(re[km], im[km]);
+          else *reinterpret_cast<float2*>(pw + 128 * (3 - r)) = make_float2(re[km], im[km]);
         }
-        if (l == 0) mbuf[0] = make_float2(re[(32 - 4 * Q) & 31], im[(32 - 4 * Q) & 31]);
         wave_sync();
-        const int idx = 4 * lq;
-        const float4 z01 = *reinterpret_cast<const float4*>(lbuf + idx);
-        const float4 z23 = *reinterpret_cast<const float4*>(lbuf + idx + 2);
-        const float4 q01 = *reinterpret_cast<const float4*>(mbuf + idx);
-        const float4 q23 = *reinterpret_cast<const float4*>(mbuf + idx + 2);
+        const float4 z01 = *reinterpret_cast<const float4*>(zr);
+        const float4 z23 = *reinterpret_cast<const float4*>(zr + kPlane1);
+        const float4 q01 = *reinterpret_cast<const float4*>(zr + kMirrorOffset);
+        const float4 q23 = *reinterpret_cast<const float4*>(zr + kMirrorOffset + kPlane1);
         uint32_t wa = 0, wb = 0;
 #define SONO_BIN(B, ZR, ZI, PR, PI)                    \
   {                                                    \
@@ -331,18 +343,18 @@ __global__ __launch_bounds__(kWaves * 64, 4) void stft1024_rgba_kernel(StftParam
             pend[Q >> 1] = cell;
           } else {
             const int kq = 32 * (Q - 1) + l + 32 * h;
-            if (4 * kq + 3 >= (int)p.bin_lo && 4 * kq < (int)p.bin_hi) slot[(kTileIters * wave + 1) * kSlotPitch + kq] = cell;
+            if (4 * kq + 3 >= (int)p.bin_lo && 4 * kq < (int)p.bin_hi) slot[(kWaves + wave) * kSlotPitch + kq] = cell;
           }
         }
       }
     }
     if (sub == 0) {
       pend_active = cur.active;
-    } else if (pend_active) {  // frame group 2*wave of the round: the cells iteration 0 kept
+    } else if (pend_active) {  // frame group `wave` of the round: the cells iteration 0 kept
 #pragma unroll
       for (int P = 0; P < 2; ++P) {
         const int kq = 64 * P + l + 32 * h;
-        if (4 * kq + 3 >= (int)p.bin_lo && 4 * kq < (int)p.bin_hi) slot[(kTileIters * wave) * kSlotPitch + kq] = pend[P];
+        if (4 * kq + 3 >= (int)p.bin_lo && 4 * kq < (int)p.bin_hi) slot[wave * kSlotPitch + kq] = pend[P];
       }
     }
     fetch(nxt);  // unconditional (an inactive unit points at frame 0): no stale values carried round the loop
