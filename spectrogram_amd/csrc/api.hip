@@ -368,8 +368,9 @@ static uint64_t in_bytes(const sono_ctx* c, uint64_t L) { return L * (c->cfg.in_
 // Which flavour of the fast kernels serves this context (StftParams::fast_mode).
 static uint32_t compute_fast_mode(const sono_ctx* c) {
   const uint32_t fn = c->cfg.fft_n;
-  if (c->cfg.arith != SONO_ARITH_FAST_F32 || (fn != 1024 && fn != 512 && fn != 2048) || c->d_fb_bin) return 0;
-  if (c->cfg.twiddle_mode == SONO_TW_ACCURATE && !c->host_twiddles) return c->d_fast ? 1 : 0;
+  if (c->cfg.arith != SONO_ARITH_FAST_F32 || (fn != 1024 && fn != 512 && fn != 2048 && fn != 4096) || c->d_fb_bin) return 0;
+  // (the 4096-point kernel has the table flavour only: accurate twiddles reach it as a table too)
+  if (fn != 4096 && c->cfg.twiddle_mode == SONO_TW_ACCURATE && !c->host_twiddles) return c->d_fast ? 1 : 0;
   // table twiddles: the kernel folds the first butterfly of every stage, so that factor must be 1
   for (uint32_t T = 1; T < c->cfg.fft_n; T <<= 1)
     if (c->h_cos[T - 1] != 1.0 || c->h_sin[T - 1] != 0.0) return 0;
@@ -445,7 +446,7 @@ static int launch_range(sono_ctx* c, const StftParams& q, const IndexScratch& au
   const bool fast = c->fast_mode != 0;
   const bool exact = c->cfg.arith == SONO_ARITH_EXACT_F64;
   const bool rgba = q.out_kind == SONO_OUT_RGBA8;
-  if (fused_ok && fast && rgba && (fast_rgba_available(qq) || fast512_rgba_available(qq) || fast2048_rgba_available(qq))) {
+  if (fused_ok && fast && rgba && (fast_rgba_available(qq) || fast512_rgba_available(qq) || fast2048_rgba_available(qq) || fast4096_rgba_available(qq))) {
     // the fast kernel writes the image itself; its rounds go through a scratch buffer sized at set-up
     if (!c->d_aux || c->d_aux_bytes < fast_rgba_scratch_bytes())
       return fail(c, SONO_ERR_ARG, "the context's image scratch is missing (tables changed without sono_set_tables?)");
@@ -453,6 +454,7 @@ static int launch_range(sono_ctx* c, const StftParams& q, const IndexScratch& au
     r = launch_stft_fast(qq, c->stream);
     if (r == 1) r = launch_stft_fast512(qq, c->stream);
     if (r == 1) r = launch_stft_fast2048(qq, c->stream);
+    if (r == 1) r = launch_stft_fast4096(qq, c->stream);
     if (r != SONO_OK) return fail(c, r, "kernel launch failed: %s", hipGetErrorString(hipGetLastError()));
     note_route(c, ":rgba");
     return SONO_OK;
@@ -493,6 +495,7 @@ static int launch_range(sono_ctx* c, const StftParams& q, const IndexScratch& au
           if (fast) r = launch_stft_fast(u, c->stream);
           if (r == 1 && fast) r = launch_stft_fast512(u, c->stream);
           if (r == 1 && fast) r = launch_stft_fast2048(u, c->stream);
+          if (r == 1 && fast) r = launch_stft_fast4096(u, c->stream);
           if (r == 1 && u.mw_ok) r = launch_stft_mw(u, c->stream);
         }
         if (r == 1) r = launch_stft_general(u, exact, c->stream);
@@ -510,6 +513,7 @@ static int launch_range(sono_ctx* c, const StftParams& q, const IndexScratch& au
   if (fast) r = launch_stft_fast(q, c->stream);
   if (r == 1 && fast) r = launch_stft_fast512(q, c->stream);
   if (r == 1 && fast) r = launch_stft_fast2048(q, c->stream);
+  if (r == 1 && fast) r = launch_stft_fast4096(q, c->stream);
   if (r == 1 && q.mw_ok) r = launch_stft_mw(q, c->stream);
   if (exact) r = launch_stft_exact(q, c->stream);
   // Feature records are integers that segmentation and species rules branch on, so they are the reference's in

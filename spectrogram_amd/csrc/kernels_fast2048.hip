@@ -302,10 +302,13 @@ __device__ __forceinline__ void epilogue_cells_table(int P, const float (&re)[32
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int lo = 16 * P + r, hi = 16 * (1 - P) + r;
-    float rl = re[lo], rh = re[hi], il = im[lo], ih = im[hi];
-    // (opaque copies: the selects below must stay selects of two registers, not become an indexed register read)
-    asm("" : "+v"(rl)); asm("" : "+v"(rh)); asm("" : "+v"(il)); asm("" : "+v"(ih));
-    c0[r * step] = make_float2(up ? rh : rl, up ? ih : il);
+    // (the select as the instruction itself: from `up ? re[hi] : re[lo]` the compiler forms an indexed register read)
+    auto pick = [](float lower, float upper) {
+      float o;
+      asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(o) : "v"(lower), "v"(upper), "s"(0xffffffff00000000ull));
+      return o;
+    };
+    c0[r * step] = make_float2(pick(re[lo], re[hi]), pick(im[lo], im[hi]));
   }
   if (k1 == 0 && up == (P == 1)) cell[kMirrorBase] = make_float2(re[16 * P], im[16 * P]);
 }

@@ -40,8 +40,6 @@ constexpr int kTwBytes = 32 * 32 * 8;
 constexpr int kWinPitch = 36;
 constexpr int kWinBytes = 32 * kWinPitch * 4;
 constexpr int kLutBytes = 1024;
-constexpr int kBlkPitch = 20;                        // floats per row of a 16 x 16 transpose block
-constexpr int kBlkFloats = 16 * kBlkPitch;
 constexpr int kWaveBytes = 4 * kBlkFloats * 4;       // 5120: four 16-lane rows
 constexpr int kQuarterBytes = kWaveBytes / 2;        // epilogue, per transform: 128 values Z[k], then 128 partners Z[N-k]
 // 128 complex values laid out for the epilogue: value j (8 bytes) of a quarter sits in plane (j >> 1) & 1 at
@@ -59,33 +57,6 @@ constexpr int kLdsBytes = kOffSlot + kSlotBytes;
 static_assert(kLdsBytes <= 160 * 1024, "LDS budget");
 
 typedef uint32_t u32x4_unaligned __attribute__((ext_vector_type(4), aligned(4)));
-
-// Transpose of one plane across the 32 lanes of a transform: lane l, register k1 -> lane k1, register l, the result
-// in the bit-reversed register order the second pass wants.  `blk` is the lane's 16-lane row block, `ll` = lane & 15.
-__device__ __forceinline__ void transpose_plane(float (&v)[32], float* __restrict__ blk, int ll) {
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {  // register bit 4 <-> lane bit 4: rows 1 / 3 of v[r] trade places with rows 0 / 2 of v[r + 16]
-    const auto s = __builtin_amdgcn_permlane16_swap(__float_as_uint(v[r]), __float_as_uint(v[r + 16]), false, false);
-    v[r] = __uint_as_float(s[0]);
-    v[r + 16] = __uint_as_float(s[1]);
-  }
-  float t[32];
-#pragma unroll
-  for (int half = 0; half < 2; ++half) {  // 16 x 16 within the 16-lane row, one half of the registers at a time
-#pragma unroll
-    for (int r = 0; r < 16; ++r) blk[r * kBlkPitch + ll] = v[16 * half + r];
-    wave_sync();
-    const float4* row = reinterpret_cast<const float4*>(blk + ll * kBlkPitch);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const float4 x = row[j];
-      t[16 * half + 4 * j] = x.x; t[16 * half + 4 * j + 1] = x.y; t[16 * half + 4 * j + 2] = x.z; t[16 * half + 4 * j + 3] = x.w;
-    }
-    wave_sync();
-  }
-#pragma unroll
-  for (int m = 0; m < 32; ++m) v[brev5(m)] = t[m];
-}
 
 // Image rows of one quarter (`part` 0..3) of a finished round: wavefront `wave` owns bins 32*wave .. +31 and writes the
 // eight rows of bins 32*wave + 8*part .. +7; lane j holds the cell of bin quad 2*part + (j & 1), frame group j >> 1
@@ -280,8 +251,8 @@ __global__ __launch_bounds__(kWaves * 64, 4) void stft1024_rgba_kernel(StftParam
           im[k1] = ui;
         }
       }
-      transpose_plane(re, blk, ll);
-      transpose_plane(im, blk, ll);
+      transpose32_plane(re, blk, ll);
+      transpose32_plane(im, blk, ll);
       if constexpr (TABLE) {
         int lt = l;
         asm volatile("" : "+v"(lt));  // (keeps 31 loop-invariant LDS addresses out of registers)

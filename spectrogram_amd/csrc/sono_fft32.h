@@ -90,6 +90,15 @@ __device__ __forceinline__ void fft32_table(float (&re)[32], float (&im)[32], Tw
   }
 }
 
+// Lane-wise select between two registers by a wave-uniform 64-bit lane mask: `if_set` where the lane's bit is 1.  (Written
+// as the instruction itself: given `cond ? a[i] : a[j]` over an unrolled loop the compiler forms an indexed register
+// read instead, and copies made opaque to prevent that cost a move each.)
+__device__ __forceinline__ float lane_select(float if_clear, float if_set, uint64_t mask) {
+  float o;
+  asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(o) : "v"(if_clear), "v"(if_set), "s"(mask));
+  return o;
+}
+
 // Orders this wavefront's LDS traffic for the compiler.  The hardware executes one wavefront's LDS
 // instructions in issue order, so data written by one lane is visible to a later read by another
 // lane of the same wavefront without a workgroup barrier.
@@ -97,6 +106,37 @@ __device__ __forceinline__ void wave_sync() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// Transposing 32 registers x 32 lanes without a 32 x 32 LDS plane: a block of 16 x 16 floats per 16-lane row.
+constexpr int kBlkPitch = 20;                 // floats per row of a block: 16-byte row reads are conflict-free
+constexpr int kBlkFloats = 16 * kBlkPitch;    // a wavefront needs four blocks (5 KiB)
+
+// Transpose of one plane across the 32 lanes of a transform: lane l, register k1 -> lane k1, register l, the result
+// in the bit-reversed register order the second pass wants.  `blk` is the lane's 16-lane row block, `ll` = lane & 15.
+__device__ __forceinline__ void transpose32_plane(float (&v)[32], float* __restrict__ blk, int ll) {
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {  // register bit 4 <-> lane bit 4: rows 1 / 3 of v[r] trade places with rows 0 / 2 of v[r + 16]
+    const auto s = __builtin_amdgcn_permlane16_swap(__float_as_uint(v[r]), __float_as_uint(v[r + 16]), false, false);
+    v[r] = __uint_as_float(s[0]);
+    v[r + 16] = __uint_as_float(s[1]);
+  }
+  float t[32];
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {  // 16 x 16 within the 16-lane row, one half of the registers at a time
+#pragma unroll
+    for (int r = 0; r < 16; ++r) blk[r * kBlkPitch + ll] = v[16 * half + r];
+    wave_sync();
+    const float4* row = reinterpret_cast<const float4*>(blk + ll * kBlkPitch);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float4 x = row[j];
+      t[16 * half + 4 * j] = x.x; t[16 * half + 4 * j + 1] = x.y; t[16 * half + 4 * j + 2] = x.z; t[16 * half + 4 * j + 3] = x.w;
+    }
+    wave_sync();
+  }
+#pragma unroll
+  for (int m = 0; m < 32; ++m) v[brev5(m)] = t[m];
 }
 
 template <typename In>

@@ -71,6 +71,11 @@ bool fast512_rgba_available(const StftParams& p);  // the kernel can write the R
 void build_fast_table_512(std::vector<float>& t);
 // kernels_fast2048.hip: the same for 2048-point frames (one complex transform per wavefront), exact roots only.
 int launch_stft_fast2048(const StftParams& p, void* hip_stream);
+// kernels_fast4096.hip: float32 kernel for 4096-point frames with table twiddles (fast_mode 2): colour indices, or the
+// RGBA image itself (given tile_scratch).  Returns 1 if it does not serve this launch.
+int launch_stft_fast4096(const StftParams& p, void* hip_stream);
+bool fast4096_available(const StftParams& p);
+bool fast4096_rgba_available(const StftParams& p);
 void build_fast_table_2048(std::vector<float>& t);
 // kernels_mw.hip: float32 kernel for 2048- and 4096-point frames with the context's twiddle table
 // (returns 1 if it does not serve this size / layout).

@@ -66,6 +66,50 @@ def test_fft4096_band_crop_rgba_fast_against_checker():
         assert ok and same >= 0.99, (route, same)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("hop,in_kind,round_frames", [(256, "f32", 32), (256, "f32", 64), (1024, "i16", 64), (204, "f32", 32),
+                                                      (1022, "f32", 0)])
+def test_fft4096_kernel_indices_and_image(hop, in_kind, round_frames, monkeypatch):
+    """The 4096-point kernel (one wavefront per frame: complex 2048-point transform of even/odd samples + the reference's
+    last stage): [frame][bin] indices within 1 LSB of the checker; the image it writes itself, at both round sizes, with
+    a band that starts and ends inside a group of four bins, equals the colour map applied to those indices.  A hop that
+    is not a multiple of four samples is served by the three-pass kernel instead (same indices within 1 LSB)."""
+    n = 4096
+    rng = np.random.default_rng(7000 + hop)
+    L = n + hop * 700 + 3
+    x = (rng.standard_normal(L) * 0.1).astype(np.float32)
+    t = np.arange(L, dtype=np.float64)
+    x += (0.4 * np.sin(0.9 * t + 2e-6 * t * t)).astype(np.float32)
+    kw, src = {}, x
+    if in_kind == "i16":
+        src = np.round(np.clip(x, -1, 1) * 32767).astype(np.int16)
+        x = (src.astype(np.float32) / 32768.0).astype(np.float32)
+        kw["in_kind"] = F.IN_I16
+    if round_frames:
+        monkeypatch.setenv("SONO_4096_ROUND", str(round_frames))
+    ref = oracle.plugin_get_frequencies(x, n, n - hop)
+    with plugin_engine(n, hop, **kw) as eng:
+        got = eng.stft(src)
+        route = eng.kernel_route()
+    assert route == ("stft4096_kernel" if hop % 4 == 0 else "stft_mw_kernel<4096>"), route
+    d = np.abs(got.astype(np.int16) - ref.astype(np.int16))
+    d = np.minimum(d, 256 - d)
+    assert got.shape == ref.shape and d.max() <= 1 and (d != 0).mean() < 0.02
+    lut = (np.arange(1024, dtype=np.uint32) * 11 % 256).astype(np.uint8)
+    for lo, hi in ((161, 1279), (0, 2048), (1030, 1034)):
+        with plugin_engine(n, hop, out_kind=F.OUT_RGBA8, bin_lo=lo, bin_hi=hi, **kw) as eng:
+            eng.set_colormap(lut)
+            img = eng.stft(src)
+            route = eng.kernel_route()
+        want = lut.reshape(256, 4)[got[:, lo:hi].T[::-1]]
+        if hop % 4 == 0:
+            assert route == "stft4096_kernel<image>:rgba", route
+            assert img.shape == want.shape and np.array_equal(img, want)          # same arithmetic, same indices
+        else:
+            assert "general" not in route, route
+            assert img.shape == want.shape and np.array_equal(img, want)
+
+
 def test_fft4096_band_crop_rgba_at_benchmark_size():
     """The same route at the benchmark's size (60 s x 384 kHz: 89 984 frames, 100 MB of indices = several chunks of
     the index buffer): the image must be the colour map applied to the [frame][bin] indices the same arithmetic

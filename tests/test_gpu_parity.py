@@ -403,7 +403,7 @@ def test_kernel_route_is_visible_and_default_view_is_fast():
         assert eng.kernel_route() == "stft1024_rgba_kernel<roots>:rgba + stft_general_kernel<float>"   # + the wrapped last frame
     with plugin_engine(4096, 256, F.ARITH_FAST_F32, out_kind=F.OUT_RGBA8, bin_lo=160, bin_hi=1280) as eng:
         eng.stft(x)
-        assert eng.kernel_route() == "stft_mw_kernel<4096>:u8 + colorize_kernel"
+        assert eng.kernel_route() == "stft4096_kernel<image>:rgba"
     with plugin_engine(256, 64, F.ARITH_FAST_F32) as eng:
         eng.stft(x)
         assert eng.kernel_route() == "stft_general_kernel<float>"
