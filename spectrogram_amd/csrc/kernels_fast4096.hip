@@ -39,9 +39,16 @@ constexpr int kTwBytes = 32 * 64 * 8;   // factors of the stages T <= 1024, [63 
 constexpr int kLastBytes = 2048 * 8;    // factors w_k of the last stage
 constexpr int kWinBytes = 4096 * 4;
 constexpr int kLutBytes = 1024;
-constexpr int kWaveBytes = 4 * kBlkFloats * 4;  // 5120: transpose blocks, then the epilogue's 256 + 257 cells of 8 bytes
+constexpr int kWaveBytes = 4 * kBlkFloats * 4;  // 4352: transpose blocks, then the epilogue's 256 + 257 cells of 8 bytes
 constexpr int kPassBins = 256;
-static_assert((2 * kPassBins + 1) * 8 <= kWaveBytes, "an epilogue pass must fit the wavefront's buffer");
+// An epilogue pass lays its 256 values (and, kRegion further on, their 256 partners) out in two planes: value j
+// (8 bytes) sits in plane (j >> 1) & 1 at 16 (j >> 2) + 8 (j & 1), so that a lane's four consecutive values are one
+// 16-byte read per plane at 16 * lane (conflict-free); the second plane starts 16 banks after the first so that the
+// 8-byte stores of 16 consecutive lanes cover 32 different banks.  (Partner 256, which nobody reads, lands in the gap.)
+constexpr int kPlane1 = 1024 + 64;
+constexpr int kRegion = kPlane1 + 1024;
+static_assert(2 * kRegion <= kWaveBytes, "an epilogue pass must fit the wavefront's buffer");
+__device__ __forceinline__ int pass_pos(int j) { return ((j >> 1) & 1) * kPlane1 + (j >> 2) * 16 + (j & 1) * 8; }
 constexpr int kOffLast = kTwBytes, kOffWin = kOffLast + kLastBytes, kOffLut = kOffWin + kWinBytes, kOffWave = kOffLut + kLutBytes;
 constexpr int kLdsBytes = kOffWave + kWaves * kWaveBytes;
 static_assert(kLdsBytes <= 160 * 1024, "LDS of one CU");
@@ -102,23 +109,24 @@ __device__ __forceinline__ void transform2048(float (&re)[32], float (&im)[32], 
   }
 }
 
-// Epilogue pass P8: Z[256 P8 + j] to cell j and the partners Z[2048 - 256 P8 - j] to cell 256 + j (j <= 256).  The bins
+// Epilogue pass P8: Z[256 P8 + j] as value j and the partners Z[2048 - 256 P8 - j] as partner j (j <= 256).  The bins
 // are registers 8 (P8 & 3) + r of the lanes of half P8 >> 2 (j = k1 + 32r), the partners registers 8 (3 - (P8 & 3)) + r of
 // the other half (j = 256 - k1 - 32r); the partner of j = 0 is one register off: Z[(2048 - 256 P8) mod 2048].
 template <int P8>
-__device__ __forceinline__ void epilogue_cells(const float (&re)[32], const float (&im)[32], float2* cell, int le) {
+__device__ __forceinline__ void epilogue_cells(const float (&re)[32], const float (&im)[32], unsigned char* buf, int le) {
   const int k1 = le & 31;
   const bool binlane = (le >> 5) == (P8 >> 2);
   constexpr uint64_t kBinLanes = (P8 >> 2) ? 0xffffffff00000000ull : 0x00000000ffffffffull;
-  float2* c0 = cell + (binlane ? k1 : 2 * kPassBins - k1);
-  const int step = binlane ? 32 : -32;
+  unsigned char* c0 = buf + (binlane ? pass_pos(k1) : kRegion + pass_pos(32 - k1) + 128 * 7);
+  const int step = binlane ? 128 : -128;  // 32 values further on = 8 quads = 128 bytes in the same plane
 #pragma unroll
   for (int r = 0; r < 8; ++r) {
     const int lo = 8 * (P8 & 3) + r, hi = 8 * (3 - (P8 & 3)) + r;
-    c0[r * step] = make_float2(lane_select(re[hi], re[lo], kBinLanes), lane_select(im[hi], im[lo], kBinLanes));
+    *reinterpret_cast<float2*>(c0 + r * step) =
+        make_float2(lane_select(re[hi], re[lo], kBinLanes), lane_select(im[hi], im[lo], kBinLanes));
   }
   constexpr int kQ = (8 - P8) & 7;  // Z[256 kQ]: lane k1 = 0 of half kQ >> 2, register 8 (kQ & 3)
-  if (k1 == 0 && (le >> 5) == (kQ >> 2)) cell[kPassBins] = make_float2(re[8 * (kQ & 3)], im[8 * (kQ & 3)]);
+  if (k1 == 0 && (le >> 5) == (kQ >> 2)) *reinterpret_cast<float2*>(buf + kRegion) = make_float2(re[8 * (kQ & 3)], im[8 * (kQ & 3)]);
 }
 
 // RGBA: the image [row = row_of_bin0 - bin][column = col0 + frame] of LUT colours (see the head of the file).
@@ -146,7 +154,7 @@ __global__ __launch_bounds__(kWaves * 64) void stft4096_kernel(StftParams p, Fas
     } else if (k < 31) {
       tw_lds[i] = tw_flat[k];  // last row: the 31 factors of the stages T = 1..16
     }
-    last_lds[i] = tw_flat[2047 + i];
+    last_lds[(i >> 1 & 1) * 1024 + (i >> 2) * 2 + (i & 1)] = tw_flat[2047 + i];  // two planes, like an epilogue pass
     win_lds[i] = p.window[i];
     win_lds[2048 + i] = p.window[2048 + i];
   }
@@ -159,7 +167,6 @@ __global__ __launch_bounds__(kWaves * 64) void stft4096_kernel(StftParams p, Fas
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   unsigned char* wbuf = smem + kOffWave + wave * kWaveBytes;
   float* blk = reinterpret_cast<float*>(wbuf) + (lane >> 4) * kBlkFloats;
-  float2* cell = reinterpret_cast<float2*>(wbuf);
   const In* __restrict__ x = reinterpret_cast<const In*>(p.pcm);
   uint8_t* __restrict__ out = reinterpret_cast<uint8_t*>(p.out);
   // blocks with equal blockIdx % 8 share an XCD (and its L2): give them neighbouring frame ranges
@@ -257,16 +264,16 @@ __global__ __launch_bounds__(kWaves * 64) void stft4096_kernel(StftParams p, Fas
       auto pass = [&](auto P8c) {
         constexpr int P8 = decltype(P8c)::value;
         if (kPassBins * (P8 + 1) <= (int)p.bin_lo || kPassBins * P8 >= (int)p.bin_hi) return;  // wave-uniform
-        epilogue_cells<P8>(re, im, cell, le);
+        epilogue_cells<P8>(re, im, wbuf, le);
         wave_sync();
-        const int j4 = 4 * le;
-        const int k = kPassBins * P8 + j4;
-        const float4 z01 = *reinterpret_cast<const float4*>(cell + j4);
-        const float4 z23 = *reinterpret_cast<const float4*>(cell + j4 + 2);
-        const float4 q01 = *reinterpret_cast<const float4*>(cell + kPassBins + j4);
-        const float4 q23 = *reinterpret_cast<const float4*>(cell + kPassBins + j4 + 2);
-        const float4 w01 = *reinterpret_cast<const float4*>(last_lds + k);
-        const float4 w23 = *reinterpret_cast<const float4*>(last_lds + k + 2);
+        const int k = kPassBins * P8 + 4 * le;
+        const unsigned char* zr = wbuf + 16 * le;
+        const float4 z01 = *reinterpret_cast<const float4*>(zr);
+        const float4 z23 = *reinterpret_cast<const float4*>(zr + kPlane1);
+        const float4 q01 = *reinterpret_cast<const float4*>(zr + kRegion);
+        const float4 q23 = *reinterpret_cast<const float4*>(zr + kRegion + kPlane1);
+        const float4 w01 = reinterpret_cast<const float4*>(last_lds)[64 * P8 + le];
+        const float4 w23 = reinterpret_cast<const float4*>(last_lds)[512 + 64 * P8 + le];
         uint32_t word = 0;
 #define SONO_BIN(B, ZR, ZI, PR, PI, WR, WI)                                  \
   {                                                                          \

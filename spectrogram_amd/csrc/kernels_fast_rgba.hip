@@ -9,11 +9,11 @@
 // memory fabric moves for this kernel (the lines are evicted from L2 between their write and their read), so it
 // lives in LDS here, and the rest of the kernel is arranged to leave room for it:
 //   * the 32 x 32 transposes between the two register passes are split: register bit 4 <-> lane bit 4 by
-//     v_permlane16_swap (no memory), the remaining 16 x 16 transposes of each 16-lane row through a 1.25 KiB block
-//     (pitch 20 floats: 16-byte row reads conflict-free), one half of the registers after the other: 5 KiB per
-//     wavefront instead of 9;
+//     v_permlane16_swap (no memory), the remaining 16 x 16 transposes of each 16-lane row through a 1 KiB block
+//     (16-byte chunks XOR-swizzled by row: stores and row reads both conflict-free), one half of the registers after
+//     the other: 4.25 KiB per wavefront instead of 9;
 //   * the epilogue pairs Z[k] with Z[N-k] in quarters of 128 bins (2 KiB per transform).
-// LDS: 8 KiB twiddle matrix + 4.5 KiB window + 1 KiB colour map + 16 x 5 KiB + 65 KiB slot = 158.5 KiB.
+// LDS: 8 KiB twiddle matrix + 4.5 KiB window + 1 KiB colour map + 16 x 4.25 KiB + 65 KiB slot = 146.5 KiB.
 //
 // One slot, two barriers per round, both between iterations.  Iteration 0 of round R+1: write out quarters 0, 1 of
 // round R (read at the end of round R), transform, keep the epilogue's two cells in registers, read quarters 2, 3 of
@@ -40,7 +40,7 @@ constexpr int kTwBytes = 32 * 32 * 8;
 constexpr int kWinPitch = 36;
 constexpr int kWinBytes = 32 * kWinPitch * 4;
 constexpr int kLutBytes = 1024;
-constexpr int kWaveBytes = 4 * kBlkFloats * 4;       // 5120: four 16-lane rows
+constexpr int kWaveBytes = 4 * kBlkFloats * 4;       // 4352: four 16-lane rows
 constexpr int kQuarterBytes = kWaveBytes / 2;        // epilogue, per transform: 128 values Z[k], then 128 partners Z[N-k]
 // 128 complex values laid out for the epilogue: value j (8 bytes) of a quarter sits in plane (j >> 1) & 1 at
 // 16 * (j >> 2) + 8 * (j & 1), so that a lane's four consecutive values are one 16-byte read per plane at 16 * lane

@@ -109,11 +109,13 @@ __device__ __forceinline__ void wave_sync() {
 }
 
 // Transposing 32 registers x 32 lanes without a 32 x 32 LDS plane: a block of 16 x 16 floats per 16-lane row.
-constexpr int kBlkPitch = 20;                 // floats per row of a block: 16-byte row reads are conflict-free
-constexpr int kBlkFloats = 16 * kBlkPitch;    // a wavefront needs four blocks (5 KiB)
+constexpr int kBlkFloats = 16 * 16 + 16;      // a block and 16 floats of bank offset to the next; a wavefront needs four (4.25 KiB)
 
 // Transpose of one plane across the 32 lanes of a transform: lane l, register k1 -> lane k1, register l, the result
 // in the bit-reversed register order the second pass wants.  `blk` is the lane's 16-lane row block, `ll` = lane & 15.
+// Element (register r, lane ll) of a block sits at float 16 r + (ll ^ 4 (r >> 2)): the 16 lanes of a store cover 16
+// consecutive banks and the neighbouring block (16 floats further on) the other 16, and the four 16-byte chunks a lane
+// reads from its row ll are the chunks c ^ (ll >> 2), which differ between the rows that share banks.
 __device__ __forceinline__ void transpose32_plane(float (&v)[32], float* __restrict__ blk, int ll) {
 #pragma unroll
   for (int r = 0; r < 16; ++r) {  // register bit 4 <-> lane bit 4: rows 1 / 3 of v[r] trade places with rows 0 / 2 of v[r + 16]
@@ -122,15 +124,16 @@ __device__ __forceinline__ void transpose32_plane(float (&v)[32], float* __restr
     v[r + 16] = __uint_as_float(s[1]);
   }
   float t[32];
+  asm volatile("" : "+v"(ll));  // (the swizzled addresses are computed here, not kept in registers round the frame loop)
 #pragma unroll
   for (int half = 0; half < 2; ++half) {  // 16 x 16 within the 16-lane row, one half of the registers at a time
 #pragma unroll
-    for (int r = 0; r < 16; ++r) blk[r * kBlkPitch + ll] = v[16 * half + r];
+    for (int r = 0; r < 16; ++r) blk[r * 16 + (ll ^ (4 * (r >> 2)))] = v[16 * half + r];
     wave_sync();
-    const float4* row = reinterpret_cast<const float4*>(blk + ll * kBlkPitch);
+    const float4* row = reinterpret_cast<const float4*>(blk + ll * 16);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const float4 x = row[j];
+      const float4 x = row[j ^ (ll >> 2)];
       t[16 * half + 4 * j] = x.x; t[16 * half + 4 * j + 1] = x.y; t[16 * half + 4 * j + 2] = x.z; t[16 * half + 4 * j + 3] = x.w;
     }
     wave_sync();
