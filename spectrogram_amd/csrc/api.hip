@@ -409,8 +409,9 @@ static int refresh_routes(sono_ctx* c) {
   c->mw_ok = compute_mw_ok(c);
   c->pair_asym = table_asymmetry(c);
   c->pair_exact = c->pair_asym <= 5e-7;
-  if (c->cfg.out_kind == SONO_OUT_RGBA8) {
-    const uint64_t want = c->fast_mode ? fast_rgba_scratch_bytes() : kDefaultChunkBytes;
+  const bool ragged_u8 = c->cfg.out_kind == SONO_OUT_U8_INDEX && ((c->bin_lo | c->bin_hi) & 3u) && (c->fast_mode || c->mw_ok);
+  if (c->cfg.out_kind == SONO_OUT_RGBA8 || ragged_u8) {
+    const uint64_t want = c->fast_mode && !ragged_u8 ? fast_rgba_scratch_bytes() : kDefaultChunkBytes;
     if (c->d_aux_bytes < want) {
       HIP_TRY(c, hipStreamSynchronize(c->stream));
       int rc = ensure(c, &c->d_aux, &c->d_aux_bytes, want);
@@ -510,11 +511,49 @@ static int launch_range(sono_ctx* c, const StftParams& q, const IndexScratch& au
       return SONO_OK;
     }
   }
-  if (fast) r = launch_stft_fast(q, c->stream);
-  if (r == 1 && fast) r = launch_stft_fast512(q, c->stream);
-  if (r == 1 && fast) r = launch_stft_fast2048(q, c->stream);
-  if (r == 1 && fast) r = launch_stft_fast4096(q, c->stream);
-  if (r == 1 && q.mw_ok) r = launch_stft_mw(q, c->stream);
+  // The float32 index and feature kernels work on whole groups of four bins.  A band that starts or ends inside a group
+  // is served by the band rounded outwards: feature records whose peak fell into the margin are recomputed by the
+  // exact-arithmetic pass below (which searches the band itself); colour indices go to a [frame][rounded bins] chunk of
+  // the context's scratch and the band's columns are copied out of it.
+  const bool ragged = !exact && (fast || q.mw_ok) && ((q.bin_lo | q.bin_hi) & 3u) && !q.fb_bin;
+  StftParams w = q;
+  if (ragged) {
+    w.bin_lo = q.bin_lo & ~3u;
+    w.bin_hi = (q.bin_hi + 3u) & ~3u;
+  }
+  if (ragged && q.out_kind == SONO_OUT_U8_INDEX && aux.ptr && aux.bytes >= 64 * (uint64_t)(w.bin_hi - w.bin_lo)) {
+    const uint64_t nb = w.bin_hi - w.bin_lo;
+    const uint64_t chunk = (aux.bytes < kMaxChunkBytes ? aux.bytes : kMaxChunkBytes) / nb / 64 * 64;  // frames per chunk
+    w.out_bins = (uint32_t)nb;
+    w.out_bin0 = w.bin_lo;
+    for (uint64_t f = 0; f < q.nframes; f += chunk) {
+      w.frame0 = q.frame0 + f;
+      w.nframes = (q.nframes - f < chunk) ? q.nframes - f : chunk;
+      w.col0 = 0;
+      w.out = aux.ptr;
+      r = 1;
+      if (w.nframes >= 16) {
+        if (fast) r = launch_stft_fast(w, c->stream);
+        if (r == 1 && fast) r = launch_stft_fast512(w, c->stream);
+        if (r == 1 && fast) r = launch_stft_fast2048(w, c->stream);
+        if (r == 1 && fast) r = launch_stft_fast4096(w, c->stream);
+        if (r == 1 && w.mw_ok) r = launch_stft_mw(w, c->stream);
+      }
+      if (r == 1) r = launch_stft_general(w, false, c->stream);
+      if (r != SONO_OK) return fail(c, r, "kernel launch failed: %s", hipGetErrorString(hipGetLastError()));
+      note_route(c, ":band");
+      uint8_t* dst = reinterpret_cast<uint8_t*>(q.out) + (q.col0 + f) * q.out_bins + (q.bin_lo - q.out_bin0);
+      HIP_TRY(c, hipMemcpy2DAsync(dst, q.out_bins, reinterpret_cast<const uint8_t*>(aux.ptr) + (q.bin_lo - w.bin_lo), nb,
+                                  q.bin_hi - q.bin_lo, w.nframes, hipMemcpyDeviceToDevice, c->stream));
+    }
+    return SONO_OK;
+  }
+  const StftParams& fq = (ragged && q.out_kind == SONO_OUT_FEATURES) ? w : q;
+  if (fast) r = launch_stft_fast(fq, c->stream);
+  if (r == 1 && fast) r = launch_stft_fast512(fq, c->stream);
+  if (r == 1 && fast) r = launch_stft_fast2048(fq, c->stream);
+  if (r == 1 && fast) r = launch_stft_fast4096(fq, c->stream);
+  if (r == 1 && q.mw_ok) r = launch_stft_mw(fq, c->stream);
   if (exact) r = launch_stft_exact(q, c->stream);
   // Feature records are integers that segmentation and species rules branch on, so they are the reference's in
   // both arithmetics: a float32 kernel marks the frames it cannot decide (two top bins too close, peak too close
@@ -602,6 +641,8 @@ static int transform(sono_ctx* c, const void* pcm, uint64_t L, void* out, uint64
   p.col0 = 0;
   p.bin_lo = c->bin_lo;
   p.bin_hi = c->bin_hi;
+  p.feat_lo = c->bin_lo;
+  p.feat_hi = c->bin_hi;
   p.row_of_bin0 = (int32_t)c->bin_hi - 1;
   rc = launch_range(c, p, aux, fused_ok);
   if (rc != SONO_OK) return rc;

@@ -376,7 +376,8 @@ __global__ __launch_bounds__(kWaves * 64) void stft512_kernel(StftParams p, Fast
           sono_frame_feature r{};
           r.peak_bin = kbest[i];
           r.peak_idx = (uint8_t)put_index<PLUGIN, 0>(best[i], fs, 0);
-          r.reserved[0] = feature_uncertain(best[i], next[i], best[i ^ 1], __builtin_fmaf(__log2f(best[i]), fs.a, fs.b), fs) ? 1 : 0;
+          r.reserved[0] = (feature_uncertain(best[i], next[i], best[i ^ 1], __builtin_fmaf(__log2f(best[i]), fs.a, fs.b), fs) ||
+                           peak_outside(kbest[i], p.feat_lo, p.feat_hi)) ? 1 : 0;
           reinterpret_cast<sono_frame_feature*>(p.out)[p.col0 + fr] = r;
         }
       }

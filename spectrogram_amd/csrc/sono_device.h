@@ -44,6 +44,11 @@ __device__ __forceinline__ uint32_t plugin_index_exact(float m, double gain, dou
 // Feature pass, reduction of per-lane (largest |X|^2, its bin, runner-up) over the `width` lanes that share a frame:
 // larger value wins, equal values go to the lower bin (the strict-> first-wins rule over ascending bins); the
 // frame's runner-up is the largest of the losers' bests and the winner's own runner-up.
+// A peak found in the band rounded outwards to groups of four bins is the band's own peak unless it sits in the margin.
+__device__ __forceinline__ bool peak_outside(int kbest, uint32_t feat_lo, uint32_t feat_hi) {
+  return kbest < (int)feat_lo || kbest >= (int)feat_hi;
+}
+
 template <int WIDTH>
 __device__ __forceinline__ void reduce_peak(float& best, int& kbest, float& next) {
   const float mine = best;

@@ -48,6 +48,9 @@ struct StftParams {
   const double* fb_w1;    // device: weight of bin fb_bin[i] + 1
   void* tile_scratch;     // device: fast_rgba_scratch_bytes() of scratch for the fused RGBA output, or nullptr
   uint32_t scale_mode, out_kind, in_kind;
+  uint32_t feat_lo, feat_hi;  // SONO_OUT_FEATURES from a float32 kernel: the band the records are for.  The kernels search whole
+                          // groups of four bins ([bin_lo, bin_hi) is that band rounded outwards) and mark a record whose
+                          // peak fell outside [feat_lo, feat_hi) for the exact-arithmetic pass, which searches the band itself
   uint32_t fixup;         // != 0: recompute only the feature records a float32 kernel marked (reserved[0] != 0); for
                           // launch_features_fixup the capacity of the queue's list
   double gain_db, range_db;

@@ -450,6 +450,40 @@ def test_features_fast_are_bit_exact_too():
     assert not ft["reserved"].any()
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,hop", [(1024, 256), (512, 128), (2048, 512), (4096, 1024)])
+def test_bands_inside_groups_of_four_bins_take_the_fast_kernels(n, hop):
+    """A band that starts and ends inside a group of four bins (the page's default view, 10-128 kHz at 384 kHz, is bins
+    26..341 of 512) is served by the float32 kernels too: colour indices through a chunk that holds the band rounded
+    outwards, feature records by searching the rounded band and recomputing every record whose peak fell into the
+    margin.  Indices within 1 LSB of the checker; feature records equal to it."""
+    rng = np.random.default_rng(n + 26)
+    L = n + hop * 900 + 11
+    x = (rng.standard_normal(L) * 0.05).astype(np.float32)
+    t = np.arange(L, dtype=np.float64)
+    lo, hi = 26 * n // 1024 + 1, 341 * n // 1024 + 2
+    # a tone that sits in the margin just below the band for a third of the signal, then sweeps through the band
+    f_margin = (lo - 1) / n
+    phase = 2 * np.pi * np.where(t < L / 3, f_margin * t, f_margin * (L / 3) + (t - L / 3) * (f_margin + (t - L / 3) * 0.25 / L))
+    x += (0.6 * np.sin(phase)).astype(np.float32)
+    idx, mags, _, _ = oracle.plugin_get_frequencies(x, n, n - hop, want_mags=True)
+    with plugin_engine(n, hop, F.ARITH_FAST_F32, bin_lo=lo, bin_hi=hi) as eng:
+        got = eng.stft(x)
+        route = eng.kernel_route()
+    assert "general" not in route and ":band" in route, route
+    d = cyc_diff(got, idx[:, lo:hi])
+    assert got.shape == (idx.shape[0], hi - lo) and d.max() <= 1 and (d != 0).mean() < 0.02
+    ref = oracle.frame_peaks_f32(mags, lo, hi)
+    with plugin_engine(n, hop, F.ARITH_FAST_F32, out_kind=F.OUT_FEATURES, bin_lo=lo, bin_hi=hi) as eng:
+        ft = eng.stft(x)
+        route = eng.kernel_route()
+        redone = eng.features_recomputed()
+    assert "fixup" in route and not route.startswith("stft_general"), route
+    assert np.array_equal(ft["peak_bin"], ref)
+    assert np.array_equal(ft["peak_idx"], idx[np.arange(len(ref)), ref])
+    assert redone >= len(ref) // 4            # the frames whose loudest bin is the tone in the margin
+
+
 def test_feature_pass_to_autoid_data():
     """bat-like signal: 5 ms down-sweeping pulses every 20 ms -> calls with falling frequency whose
     measured fields are valid matcher input."""
