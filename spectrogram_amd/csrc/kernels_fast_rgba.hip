@@ -13,13 +13,25 @@
 //     (16-byte chunks XOR-swizzled by row: stores and row reads both conflict-free), one half of the registers after
 //     the other: 4.25 KiB per wavefront instead of 9;
 //   * the epilogue pairs Z[k] with Z[N-k] in quarters of 128 bins (2 KiB per transform).
-// LDS: 8 KiB twiddle matrix + 4.5 KiB window + 1 KiB colour map + 16 x 4.25 KiB + 65 KiB slot = 146.5 KiB.
+// LDS: 8 KiB twiddle matrix + 4.5 KiB window + 1 KiB colour map + 16 x 4.25 KiB + 74 KiB slot = 155.5 KiB.
 //
-// One slot, two barriers per round, both between iterations.  Iteration 0 of round R+1: write out quarters 0, 1 of
-// round R (read at the end of round R), transform, keep the epilogue's two cells in registers, read quarters 2, 3 of
-// round R.  Iteration 1: BARRIER (every wavefront has taken what it needs of round R out of the slot), write out
-// quarters 2, 3, transform, store the kept cells and this epilogue's cells into the slot, BARRIER (slot complete), read
-// quarters 0, 1 of round R+1.  Across a transform a lane holds 8 registers of parked or pending indices.
+// Whole 64-byte sectors only.  The image's row pitch (4 x width bytes) is no multiple of 64 bytes, so a 512-byte run
+// that starts at a round boundary straddles sector boundaries at both ends, and the two halves of such a sector come
+// from different rounds at different times: written with the runs cut at the round boundaries, the same image takes
+// 4.2 ms to store (stores alone, no transform); cut at sector boundaries 2.9 ms.  So a workgroup owns a CONTIGUOUS
+// range of frames, and the run of a row in a round starts `e` frames before the round, e = 0..15 chosen per row so
+// that the run starts on a sector boundary: the last e indices of the round before are still in the slot.  The slot
+// is one ring of 144 frames per bin row (36 dwords of four frames each, byte = frame): round k occupies dwords
+// 32k .. 32k+31 (mod 36), which leaves the last 16 frames of round k-1 in place.  A lane reads two neighbouring dwords
+// of its row and v_alignbyte_b32 cuts the four frames it stores out of them.  Partial sectors remain only where the
+// ranges of two workgroups meet (each masks the frames that are not its own) and at the ends of the recording.
+//
+// One slot, two barriers per round, both between iterations.  Iteration 0 of round k+1: write out quarters 0, 1 of
+// round k (read at the end of round k), transform, keep the epilogue's indices in registers, read quarters 2, 3 of
+// round k.  Iteration 1: BARRIER (every wavefront has taken what it needs of round k out of the slot), write out
+// quarters 2, 3, transform, store the kept indices and this epilogue's into the slot, BARRIER (slot complete), read
+// quarters 0, 1 of round k+1.  After its last round a workgroup runs two more, empty ones: they write out the last
+// round and the e frames per row that it left behind.
 #include <hip/hip_runtime.h>
 
 #include "sono_device.h"
@@ -50,19 +62,33 @@ constexpr int kPlane1 = 512 + 64;
 constexpr int kMirrorOffset = kPlane1 + 512;
 static_assert(2 * kMirrorOffset <= kQuarterBytes, "an epilogue quarter must fit half the wavefront's slice");
 __device__ __forceinline__ int quarter_pos(int j) { return ((j >> 1) & 1) * kPlane1 + (j >> 2) * 16 + (j & 1) * 8; }
-constexpr int kSlotPitch = 130;                      // 16-byte cells per frame group: 128 bin quads + 2 (bank spread of the read-out)
-constexpr int kSlotBytes = 32 * kSlotPitch * 16;
+constexpr int kRingDwords = 36;                      // per bin row: 144 frames, four per dword
+constexpr int kRowPitch = 37;                        // dwords per bin row (odd: the stores of a bin quad's rows spread over banks)
+constexpr int kSlotBytes = 512 * kRowPitch * 4;
 constexpr int kOffWin = kTwBytes, kOffLut = kOffWin + kWinBytes, kOffWave = kOffLut + kLutBytes, kOffSlot = kOffWave + kWaves * kWaveBytes;
 constexpr int kLdsBytes = kOffSlot + kSlotBytes;
 static_assert(kLdsBytes <= 160 * 1024, "LDS budget");
 
 typedef uint32_t u32x4_unaligned __attribute__((ext_vector_type(4), aligned(4)));
 
-// Image rows of one quarter (`part` 0..3) of a finished round: wavefront `wave` owns bins 32*wave .. +31 and writes the
-// eight rows of bins 32*wave + 8*part .. +7; lane j holds the cell of bin quad 2*part + (j & 1), frame group j >> 1
-// (4 bins x 4 frames) and stores four 16-byte pixel runs; 32 lanes form the 512-byte run of a row.
-__device__ __forceinline__ void flush_cell(const StftParams& p, const uint4& q, const uint32_t* lut_lds, uint64_t frame0, int part,
-                                           int wave, int lane) {
+// What the image writer needs to know about the workgroup's range of frames.
+struct Range {
+  uint64_t f_lo, f_hi;  // frames [f_lo, f_hi) are this workgroup's
+  uint32_t align_px;    // (address of pixel (row 0, frame f_lo) / 4) mod 16
+};
+
+// The run of bin row `bin` starts e = 0..15 frames before a round, so that it starts on a 64-byte boundary.
+__device__ __forceinline__ int row_lead(const StftParams& p, const Range& rg, int bin) {
+  const uint32_t row = (uint32_t)(p.row_of_bin0 - bin);
+  return (int)((rg.align_px + (row & 15u) * ((uint32_t)p.width & 15u)) & 15u);
+}
+
+// Image rows of one quarter (`part` 0..3) of the round that starts at frame `fround`: wavefront `wave` owns bins
+// 32*wave .. +31 and writes the eight rows of bins 32*wave + 8*part .. +7; lane j stores four pixels (16 bytes) of the rows
+// 4*(j & 1) + i, i = 0..3, of the quarter: frames fround - e + 4*(j >> 1) .. +3; 32 lanes form the 512-byte run of a row.
+// d[i] holds those four frames' indices, byte t = frame + t (read_rows).
+__device__ __forceinline__ void flush_rows(const StftParams& p, const Range& rg, const uint32_t (&d)[4], const uint32_t* lut_lds,
+                                           uint64_t fround, int part, int wave, int lane) {
   asm volatile("" : "+s"(wave));   // (everything below is loop-invariant; computed in place it costs a few instructions,
   asm volatile("" : "+v"(lane));   //  hoisted it would hold registers the transforms need)
   const int qsel = lane & 1, fsel = lane >> 1;
@@ -70,29 +96,42 @@ __device__ __forceinline__ void flush_cell(const StftParams& p, const uint4& q, 
   const int bin0 = 32 * wave + 8 * part;
   if (bin0 + 8 <= (int)p.bin_lo || bin0 >= (int)p.bin_hi) return;
   const int binq = bin0 + 4 * qsel;
-  const bool whole = frame0 + kRoundFrames <= p.nframes;  // workgroup-uniform
-  const uint64_t fl = frame0 + 4 * fsel;
-  const int nvalid = fl >= p.nframes ? 0 : (p.nframes - fl >= 4 ? 4 : (int)(p.nframes - fl));
-  uint8_t* __restrict__ base = reinterpret_cast<uint8_t*>(p.out) + (int64_t)(p.col0 + frame0) * 4 +
+  uint8_t* __restrict__ base = reinterpret_cast<uint8_t*>(p.out) + (int64_t)(p.col0 + fround) * 4 +
                                (int64_t)(p.row_of_bin0 - binq) * width4 + 16 * fsel;
+  // e of consecutive rows differs by the width (mod 16)
+  const uint32_t wstep = (uint32_t)p.width & 15u;
+  uint32_t e = (uint32_t)row_lead(p, rg, binq);
+  // wave-uniform: every row of the quarter is in the band and every frame it writes is this workgroup's
+  const bool plain = bin0 >= (int)p.bin_lo && bin0 + 8 <= (int)p.bin_hi && fround >= rg.f_lo + 16 && fround + kRoundFrames <= rg.f_hi;
+  if (plain) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const uint32_t v = d[i];
+      u32x4_unaligned px;
+      px.x = lut_lds[v & 255u];
+      px.y = lut_lds[(v >> 8) & 255u];
+      px.z = lut_lds[(v >> 16) & 255u];
+      px.w = lut_lds[v >> 24];
+      *reinterpret_cast<u32x4_unaligned*>(base - (int64_t)i * width4 - 4 * (int)e) = px;
+      e = (e - wstep) & 15u;  // the next bin is one row up
+    }
+    return;
+  }
+  // (frames relative to the start of the range: an image is at most 2^24 columns wide)
+  const int rel0 = (int)(fround - rg.f_lo) + 4 * fsel, span = (int)(rg.f_hi - rg.f_lo);
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
+    const uint32_t ei = e;
+    e = (e - wstep) & 15u;
     if (binq + i < (int)p.bin_lo || binq + i >= (int)p.bin_hi) continue;
-    u32x4_unaligned px;
-    px.x = lut_lds[(q.x >> (8 * i)) & 255u];
-    px.y = lut_lds[(q.y >> (8 * i)) & 255u];
-    px.z = lut_lds[(q.z >> (8 * i)) & 255u];
-    px.w = lut_lds[(q.w >> (8 * i)) & 255u];
-    uint8_t* dst = base - (int64_t)i * width4;
-    if (whole) {
-      *reinterpret_cast<u32x4_unaligned*>(dst) = px;
-    } else {  // the last round of the recording
-      uint32_t* d = reinterpret_cast<uint32_t*>(dst);
-      if (nvalid > 0) d[0] = px.x;
-      if (nvalid > 1) d[1] = px.y;
-      if (nvalid > 2) d[2] = px.z;
-      if (nvalid > 3) d[3] = px.w;
-    }
+    const uint32_t v = d[i];
+    const uint32_t px[4] = {lut_lds[v & 255u], lut_lds[(v >> 8) & 255u], lut_lds[(v >> 16) & 255u], lut_lds[v >> 24]};
+    uint32_t* o = reinterpret_cast<uint32_t*>(base - (int64_t)i * width4 - 4 * (int)ei);
+    const int f = rel0 - (int)ei;
+    // where the range begins or ends: only the frames that are this workgroup's
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+      if (f + t >= 0 && f + t < span) o[t] = px[t];
   }
 }
 
@@ -106,7 +145,7 @@ __global__ __launch_bounds__(kWaves * 64, 4) void stft1024_rgba_kernel(StftParam
   float2* tw_lds = reinterpret_cast<float2*>(smem);
   float* win_lds = reinterpret_cast<float*>(smem + kOffWin);
   uint32_t* lut_lds = reinterpret_cast<uint32_t*>(smem + kOffLut);
-  uint4* slot = reinterpret_cast<uint4*>(smem + kOffSlot);
+  uint32_t* slot = reinterpret_cast<uint32_t*>(smem + kOffSlot);
   const float2* __restrict__ tw_flat = reinterpret_cast<const float2*>(p.twiddles);
   for (int i = threadIdx.x; i < 1024; i += kThreads) {
     if constexpr (TABLE) {
@@ -139,9 +178,14 @@ __global__ __launch_bounds__(kWaves * 64, 4) void stft1024_rgba_kernel(StftParam
   const uint32_t per = gridDim.x >> 3;
   const uint32_t vb = (gridDim.x & 7) ? blockIdx.x : (blockIdx.x & 7) * per + (blockIdx.x >> 3);
   // every workgroup runs the same number of rounds and every wavefront goes through every round (with or without
-  // frames of its own), because the rounds are fenced by workgroup barriers
-  const uint64_t ntiles = (p.nframes + kTileFrames - 1) / kTileFrames;
-  const uint64_t rounds = (ntiles + (uint64_t)gridDim.x * kWaves - 1) / ((uint64_t)gridDim.x * kWaves);
+  // frames of its own), because the rounds are fenced by workgroup barriers; a workgroup's rounds are consecutive frames
+  const uint64_t nrounds = (p.nframes + kRoundFrames - 1) / kRoundFrames;
+  const uint64_t rounds = (nrounds + gridDim.x - 1) / gridDim.x;
+  Range rg;
+  rg.f_lo = (uint64_t)vb * rounds * kRoundFrames;
+  rg.f_hi = rg.f_lo + rounds * kRoundFrames < p.nframes ? rg.f_lo + rounds * kRoundFrames : p.nframes;
+  if (rg.f_hi < rg.f_lo) rg.f_hi = rg.f_lo;
+  rg.align_px = (uint32_t)((reinterpret_cast<uintptr_t>(p.out) >> 2) + p.col0 + rg.f_lo) & 15u;
 
   struct Unit {
     uint64_t f0;
@@ -153,9 +197,9 @@ __global__ __launch_bounds__(kWaves * 64, 4) void stft1024_rgba_kernel(StftParam
     Unit u;
     // frame group (4 frames) 16 * sub + wave of the round: the 16 wavefronts of an iteration read one contiguous span
     // of samples, so the 3/4 overlap between neighbouring groups is re-read while it is still in cache
-    const uint64_t group = (((it / kTileIters) * gridDim.x + vb) * kTileIters + it % kTileIters) * kWaves + wave;
+    const uint64_t group = ((uint64_t)vb * rounds * kTileIters + it) * kWaves + wave;
     const uint64_t pair0 = group * 2;
-    u.active = pair0 < npairs;  // wave-uniform
+    u.active = it < rounds * kTileIters && pair0 < npairs;  // wave-uniform
     if (!u.active) {            // nothing left: point at frame 0 so that the sample loads stay in bounds
       u.f0 = 0;
       u.st_a = u.st_b = u.shifted = false;
@@ -190,21 +234,58 @@ __global__ __launch_bounds__(kWaves * 64, 4) void stft1024_rgba_kernel(StftParam
       }
     }
   };
-  // this lane's parked cells of the two quarters the next iteration writes out
-  auto read_cells = [&](uint4 (&fq)[2], int first_part) {
+  // this lane's four frames of each of its rows, for the two quarters the next iteration writes out of round k (of this
+  // workgroup): row 4*(j & 1) + i of the quarter, frames 128k - e + 4*(j >> 1) .. +3, cut out of two neighbouring ring dwords
+  auto read_rows = [&](uint32_t (&fq)[2][4], int first_part, uint64_t k) {
     int w = wave, j = lane;
     asm volatile("" : "+s"(w));
     asm volatile("" : "+v"(j));
+    const int ringpos = (int)((32 * k) % kRingDwords);  // first dword of round k
+    const uint32_t wstep = (uint32_t)p.width & 15u;
 #pragma unroll
-    for (int q = 0; q < 2; ++q) fq[q] = slot[(j >> 1) * kSlotPitch + 8 * w + 2 * (first_part + q) + (j & 1)];
+    for (int q = 0; q < 2; ++q) {
+      uint32_t e = (uint32_t)row_lead(p, rg, 32 * w + 8 * (first_part + q) + 4 * (j & 1));
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int bin = 32 * w + 8 * (first_part + q) + 4 * (j & 1) + i;
+        int d0 = ringpos + (j >> 1) - (int)((e + 3) >> 2);  // -4 .. 66
+        const uint32_t shift = (0u - e) & 3u;
+        e = (e - wstep) & 15u;                               // the next bin is one row up
+        d0 += d0 < 0 ? kRingDwords : 0;
+        d0 -= d0 >= kRingDwords ? kRingDwords : 0;
+        int d1 = d0 + 1;
+        d1 -= d1 >= kRingDwords ? kRingDwords : 0;
+        const uint32_t* row = slot + bin * kRowPitch;
+        fq[q][i] = __builtin_amdgcn_alignbyte(row[d1], row[d0], shift);  // byte t = frame + t
+      }
+    }
+  };
+  // The indices of four frames x four bins as the epilogue leaves them (word = frame, byte = bin) turned into word = bin,
+  // byte = frame: what the ring rows hold.
+  auto turn = [](uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3, uint32_t (&r)[4]) {
+    const uint32_t t0 = __builtin_amdgcn_perm(w1, w0, 0x05010400u), t1 = __builtin_amdgcn_perm(w1, w0, 0x07030602u);
+    const uint32_t t2 = __builtin_amdgcn_perm(w3, w2, 0x05010400u), t3 = __builtin_amdgcn_perm(w3, w2, 0x07030602u);
+    r[0] = __builtin_amdgcn_perm(t2, t0, 0x05040100u);
+    r[1] = __builtin_amdgcn_perm(t2, t0, 0x07060302u);
+    r[2] = __builtin_amdgcn_perm(t3, t1, 0x05040100u);
+    r[3] = __builtin_amdgcn_perm(t3, t1, 0x07060302u);
+  };
+  // frame group fg (0..31) of round k, bin quad kq: one dword into each of the quad's four rows
+  auto park = [&](const uint32_t (&r)[4], uint64_t k, int fg, int kq) {
+    if (4 * kq + 3 < (int)p.bin_lo || 4 * kq >= (int)p.bin_hi) return;
+    int d = (int)((32 * k) % kRingDwords) + fg;
+    d -= d >= kRingDwords ? kRingDwords : 0;
+    uint32_t* row = slot + 4 * kq * kRowPitch + d;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) row[b * kRowPitch] = r[b];
   };
 
   Unit cur = locate(0);
   fetch(cur);
-  uint4 fq[2] = {};    // parked cells of the two quarters the next iteration writes out
-  uint4 pend[2] = {};  // cells of iteration 0's epilogue, stored into the slot in iteration 1
+  uint32_t fq[2][4] = {};     // indices of the two quarters the next iteration writes out
+  uint32_t pend[2][4] = {};   // indices of iteration 0's epilogue, stored into the slot in iteration 1
   bool pend_active = false;
-  for (uint64_t it = 0; it < (rounds + 1) * kTileIters; ++it) {
+  for (uint64_t it = 0; it < (rounds + 2) * kTileIters; ++it) {
     const uint64_t round = it / kTileIters;
     const int sub = (int)(it % kTileIters);
     const Unit nxt = locate(it + 1);
@@ -215,12 +296,10 @@ __global__ __launch_bounds__(kWaves * 64, 4) void stft1024_rgba_kernel(StftParam
     // of this iteration, and not behind them)
 #pragma unroll
     for (int a = 0; a < kRaw; ++a) asm volatile("" : "+v"(raw[a]));
-    if (round > 0) {
-      const uint64_t frame0 = ((round - 1) * gridDim.x + vb) * kRoundFrames;
-      if (frame0 < p.nframes) {
-        flush_cell(p, fq[0], lut_lds, frame0, 2 * sub, wave, lane);
-        flush_cell(p, fq[1], lut_lds, frame0, 2 * sub + 1, wave, lane);
-      }
+    if (round > 0 && rg.f_lo < rg.f_hi) {
+      const uint64_t fround = rg.f_lo + (round - 1) * kRoundFrames;
+      flush_rows(p, rg, fq[0], lut_lds, fround, 2 * sub, wave, lane);
+      flush_rows(p, rg, fq[1], lut_lds, fround, 2 * sub + 1, wave, lane);
     }
 
     if (cur.active) {
@@ -309,12 +388,12 @@ __global__ __launch_bounds__(kWaves * 64, 4) void stft1024_rgba_kernel(StftParam
           // and 64P + 32 + l (quarter 2P + 1); after: lane (l, h) holds the quad 64P + l + 32h of all four frames
           const auto sa = __builtin_amdgcn_permlane32_swap(wa2[0], wa2[1], false, false);
           const auto sb = __builtin_amdgcn_permlane32_swap(wb2[0], wb2[1], false, false);
-          const uint4 cell = make_uint4(sa[0], sb[0], sa[1], sb[1]);
           if (sub == 0) {
-            pend[Q >> 1] = cell;
+            turn(sa[0], sb[0], sa[1], sb[1], pend[Q >> 1]);
           } else {
-            const int kq = 32 * (Q - 1) + l + 32 * h;
-            if (4 * kq + 3 >= (int)p.bin_lo && 4 * kq < (int)p.bin_hi) slot[(kWaves + wave) * kSlotPitch + kq] = cell;
+            uint32_t r4[4];
+            turn(sa[0], sb[0], sa[1], sb[1], r4);
+            park(r4, round, kWaves + wave, 32 * (Q - 1) + l + 32 * h);
           }
         }
       }
@@ -323,21 +402,19 @@ __global__ __launch_bounds__(kWaves * 64, 4) void stft1024_rgba_kernel(StftParam
       pend_active = cur.active;
     } else if (pend_active) {  // frame group `wave` of the round: the cells iteration 0 kept
 #pragma unroll
-      for (int P = 0; P < 2; ++P) {
-        const int kq = 64 * P + l + 32 * h;
-        if (4 * kq + 3 >= (int)p.bin_lo && 4 * kq < (int)p.bin_hi) slot[wave * kSlotPitch + kq] = pend[P];
-      }
+      for (int P = 0; P < 2; ++P) park(pend[P], round, wave, 64 * P + l + 32 * h);
     }
     fetch(nxt);  // unconditional (an inactive unit points at frame 0): no stale values carried round the loop
     cur = nxt;
 
     if (sub == 0) {
       // the slot still holds the previous round: take the last two quarters of this wavefront's 32 rows
-      if (round > 0 && round <= rounds) read_cells(fq, 2);
+      if (round > 0) read_rows(fq, 2, round - 1);
     } else {
-      // the round's slot is complete once every wavefront is here; then take the first two quarters
+      // the round's slot is complete once every wavefront is here; then take the first two quarters (after the last
+      // round: of the empty round that only has the frames the last one left behind)
       __syncthreads();
-      if (round < rounds) read_cells(fq, 0);
+      if (round <= rounds) read_rows(fq, 0, round);
     }
   }
 }
