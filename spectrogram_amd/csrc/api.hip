@@ -10,6 +10,7 @@
 #include <string>
 #include <vector>
 
+#include "sono_device.h"
 #include "sono_internal.h"
 #include "sonospec.h"
 
@@ -46,6 +47,8 @@ struct sono_ctx {
   // facts about the tables that choose the kernel; recomputed whenever a table changes (refresh_routes)
   uint32_t fast_mode = 0;   // StftParams::fast_mode
   bool mw_ok = false;       // StftParams::mw_ok
+  uint32_t fb_fast_mode = 0;  // with a filter bank installed: the same two for the magnitude pass in front of it
+  bool fb_mw_ok = false;
   bool pair_exact = false;  // StftParams::pair_exact
   double pair_asym = 0;     // StftParams::pair_asym
   std::string route;        // kernels of the most recent transform call (sono_kernel_route)
@@ -366,9 +369,10 @@ uint64_t sono_out_bytes(const sono_ctx* c, uint64_t L) {
 static uint64_t in_bytes(const sono_ctx* c, uint64_t L) { return L * (c->cfg.in_kind == SONO_IN_I16 ? 2 : 4); }
 
 // Which flavour of the fast kernels serves this context (StftParams::fast_mode).
-static uint32_t compute_fast_mode(const sono_ctx* c) {
+static uint32_t compute_fast_mode(const sono_ctx* c, bool with_filterbank = false) {
   const uint32_t fn = c->cfg.fft_n;
-  if (c->cfg.arith != SONO_ARITH_FAST_F32 || (fn != 1024 && fn != 512 && fn != 2048 && fn != 4096) || c->d_fb_bin) return 0;
+  if (c->cfg.arith != SONO_ARITH_FAST_F32 || (fn != 1024 && fn != 512 && fn != 2048 && fn != 4096) || (c->d_fb_bin && !with_filterbank))
+    return 0;
   // (the 4096-point kernel has the table flavour only: accurate twiddles reach it as a table too)
   if (fn != 4096 && c->cfg.twiddle_mode == SONO_TW_ACCURATE && !c->host_twiddles) return c->d_fast ? 1 : 0;
   // table twiddles: the kernel folds the first butterfly of every stage, so that factor must be 1
@@ -390,8 +394,9 @@ static double table_asymmetry(const sono_ctx* c) {
   return worst;
 }
 // The 512/2048/4096-point three-pass kernel takes any twiddle table whose stages start with the factor (1, 0).
-static bool compute_mw_ok(const sono_ctx* c) {
-  if (c->cfg.arith != SONO_ARITH_FAST_F32 || (c->cfg.fft_n != 512 && c->cfg.fft_n != 2048 && c->cfg.fft_n != 4096) || c->d_fb_bin)
+static bool compute_mw_ok(const sono_ctx* c, bool with_filterbank = false) {
+  if (c->cfg.arith != SONO_ARITH_FAST_F32 || (c->cfg.fft_n != 512 && c->cfg.fft_n != 2048 && c->cfg.fft_n != 4096) ||
+      (c->d_fb_bin && !with_filterbank))
     return false;
   for (uint32_t T = 1; T < c->cfg.fft_n; T <<= 1)
     if (c->h_cos[T - 1] != 1.0 || c->h_sin[T - 1] != 0.0) return false;
@@ -407,10 +412,13 @@ constexpr uint64_t kMaxChunkBytes = (uint64_t)96 << 20;
 static int refresh_routes(sono_ctx* c) {
   c->fast_mode = compute_fast_mode(c);
   c->mw_ok = compute_mw_ok(c);
+  c->fb_fast_mode = c->d_fb_bin ? compute_fast_mode(c, true) : 0;
+  c->fb_mw_ok = c->d_fb_bin ? compute_mw_ok(c, true) : false;
   c->pair_asym = table_asymmetry(c);
   c->pair_exact = c->pair_asym <= 5e-7;
   const bool ragged_u8 = c->cfg.out_kind == SONO_OUT_U8_INDEX && ((c->bin_lo | c->bin_hi) & 3u) && (c->fast_mode || c->mw_ok);
-  if (c->cfg.out_kind == SONO_OUT_RGBA8 || ragged_u8) {
+  const bool fb_route = (c->fb_fast_mode || c->fb_mw_ok) && (c->cfg.out_kind == SONO_OUT_RGBA8 || c->cfg.out_kind == SONO_OUT_U8_INDEX);
+  if (c->cfg.out_kind == SONO_OUT_RGBA8 || ragged_u8 || fb_route) {
     const uint64_t want = c->fast_mode && !ragged_u8 ? fast_rgba_scratch_bytes() : kDefaultChunkBytes;
     if (c->d_aux_bytes < want) {
       HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -506,6 +514,61 @@ static int launch_range(sono_ctx* c, const StftParams& q, const IndexScratch& au
                             (uint8_t*)q.out, q.width, q.col0 + f, c->stream);
         if (r != SONO_OK) return fail(c, r, "colorize launch failed");
         sono::note_kernel("colorize_kernel");
+        note_route(c);
+      }
+      return SONO_OK;
+    }
+  }
+  // Non-linear frequency scales in the float32 arithmetic: the float32 transform kernel writes a chunk of magnitudes
+  // ([frame][n/2] float32, in the context's scratch), the filter-bank kernel gathers its two taps per output bin from it
+  // and quantises; for the image a chunk of indices and the colour-map kernel follow.
+  if (q.fb_bin && !exact && (c->fb_fast_mode || c->fb_mw_ok) && aux.ptr &&
+      (q.out_kind == SONO_OUT_U8_INDEX || (rgba && q.row_of_bin0 == (int32_t)q.bin_hi - 1))) {
+    const uint32_t half = q.n / 2;
+    const uint32_t lo4 = q.bin_lo & ~3u, hi4 = (q.bin_hi + 3u) & ~3u, nb4 = hi4 - lo4;
+    const uint64_t per_frame = (uint64_t)half * 4 + (rgba ? nb4 : 0);
+    uint64_t chunk = (aux.bytes < kMaxChunkBytes ? aux.bytes : kMaxChunkBytes) / per_frame / 64 * 64;  // frames per chunk
+    if (aux.single_chunk) chunk = q.nframes * per_frame <= aux.bytes ? q.nframes : 0;
+    if (chunk) {
+      float* mags = reinterpret_cast<float*>(aux.ptr);
+      uint8_t* idx = reinterpret_cast<uint8_t*>(aux.ptr) + chunk * half * 4;
+      const FastScale fs = make_fast_scale(q.scale_mode, q.n, q.gain_db, q.range_db);
+      for (uint64_t f = 0; f < q.nframes; f += chunk) {
+        StftParams m = q;
+        m.fb_bin = nullptr;
+        m.fb_w0 = m.fb_w1 = nullptr;
+        m.lut = nullptr;
+        m.out_kind = SONO_OUT_F32_MAG;
+        m.bin_lo = 0;
+        m.bin_hi = half;
+        m.out_bins = half;
+        m.out_bin0 = 0;
+        m.frame0 = q.frame0 + f;
+        m.nframes = (q.nframes - f < chunk) ? q.nframes - f : chunk;
+        m.col0 = 0;
+        m.out = mags;
+        m.fast_mode = c->fb_fast_mode;
+        m.mw_ok = c->fb_mw_ok ? 1u : 0u;
+        m.pair_exact = 1;  // (the cross-talk of an asymmetric table is far below a step of the quantiser)
+        r = 1;
+        if (m.nframes >= 16) {
+          if (m.fast_mode) r = launch_stft_fast(m, c->stream);
+          if (r == 1 && m.mw_ok) r = launch_stft_mw(m, c->stream);
+        }
+        if (r == 1) r = launch_stft_general(m, false, c->stream);
+        if (r != SONO_OK) return fail(c, r, "kernel launch failed: %s", hipGetErrorString(hipGetLastError()));
+        note_route(c, ":mag");
+        if (rgba) {
+          r = launch_filterbank_index(mags, m.nframes, half, q.fb_bin, q.fb_w0, q.fb_w1, lo4, hi4, nb4, lo4, 0, fs, q.n, idx, c->stream);
+          if (r == SONO_OK)
+            r = launch_colorize(idx, m.nframes, nb4, hi4 - q.bin_hi, q.bin_hi - q.bin_lo, q.lut, (uint8_t*)q.out, q.width, q.col0 + f,
+                                c->stream);
+        } else {
+          r = launch_filterbank_index(mags, m.nframes, half, q.fb_bin, q.fb_w0, q.fb_w1, q.bin_lo, q.bin_hi, q.out_bins, q.out_bin0,
+                                      q.col0 + f, fs, q.n, reinterpret_cast<uint8_t*>(q.out), c->stream);
+        }
+        if (r != SONO_OK) return fail(c, r, "filter-bank launch failed");
+        sono::note_kernel(rgba ? "filterbank_index_kernel + colorize_kernel" : "filterbank_index_kernel");
         note_route(c);
       }
       return SONO_OK;

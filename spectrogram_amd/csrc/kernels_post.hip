@@ -3,6 +3,7 @@
 // double in the reference's order).
 #include <hip/hip_runtime.h>
 
+#include "sono_device.h"
 #include "sono_internal.h"
 #include "sono_launch.h"
 
@@ -367,6 +368,69 @@ uint64_t launch_valu_peak(float* sink, uint32_t iterations, void* stream_v) {
   const int cus = device_cu_count();
   hipLaunchKernelGGL(valu_peak_kernel, dim3(cus), dim3(1024), 0, stream, sink, iterations, 0.999f, 0.001f);
   return (uint64_t)cus * 16 * iterations * kPeakUnroll * kPeakChains;
+}
+
+// Non-linear frequency scales in the float32 arithmetic: out[y] = m[o] * w0[y] + m[o + 1] * w1[y] with o = fb_bin[y], over a
+// [frame][half] plane of float32 magnitudes, then the plugin quantiser.  One NaN or infinite magnitude turns every bin of
+// its frame NaN: the reference's accumulator adds m[s] * bank[y][s] for EVERY bin s, and NaN * 0 is NaN
+// (spectrogram.esm.js:479-488).  One wavefront per frame; tap tables and the frame's magnitudes in LDS.
+__global__ __launch_bounds__(256) void filterbank_index_kernel(const float* __restrict__ mags, uint64_t nframes, uint32_t half,
+                                                               const int32_t* __restrict__ fb_bin, const double* __restrict__ w0,
+                                                               const double* __restrict__ w1, uint32_t bin_lo, uint32_t bin_hi,
+                                                               uint32_t out_bins, uint32_t out_bin0, uint64_t col0, FastScale fs,
+                                                               float unscale, uint8_t* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  int32_t* tap = reinterpret_cast<int32_t*>(smem);
+  float* wa = reinterpret_cast<float*>(tap + half);
+  float* wb = wa + half;
+  float* frames = wb + half;  // [4][half]
+  for (uint32_t y = threadIdx.x; y < half; y += 256) {
+    tap[y] = fb_bin[y];
+    wa[y] = (float)w0[y];
+    wb[y] = (float)w1[y];
+  }
+  __syncthreads();
+  const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  float* m = frames + wave * half;
+  for (uint64_t f = (uint64_t)blockIdx.x * 4 + wave; f < nframes; f += (uint64_t)gridDim.x * 4) {
+    const float* row = mags + f * half;
+    int bad = 0;
+    for (uint32_t y = lane; y < half; y += 64) {
+      const float v = row[y];
+      m[y] = v;
+      bad |= !isfinite(v);
+    }
+    bad = __any(bad);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    uint8_t* orow = out + (col0 + f) * out_bins - out_bin0;
+    for (uint32_t y = bin_lo + lane; y < bin_hi; y += 64) {
+      const int32_t o = tap[y];
+      float acc = 0.0f;
+      if (o >= 0 && o < (int32_t)half) acc = m[o] * wa[y];
+      if (o + 1 >= 0 && o + 1 < (int32_t)half) acc += m[o + 1] * wb[y];
+      if (bad) acc = __builtin_nanf("");
+      const float x = acc * unscale;  // fast_index takes |X|^2 before the 2/N scaling
+      orow[y] = (uint8_t)fast_index(x * x, fs);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
+}
+
+int launch_filterbank_index(const float* mags, uint64_t nframes, uint32_t half, const int32_t* fb_bin, const double* w0, const double* w1,
+                            uint32_t bin_lo, uint32_t bin_hi, uint32_t out_bins, uint32_t out_bin0, uint64_t col0, const FastScale& fs,
+                            uint32_t n, uint8_t* out, void* hip_stream) {
+  if (!mags || !fb_bin || !w0 || !w1 || !out || bin_lo >= bin_hi || bin_hi > half) return SONO_ERR_ARG;
+  const size_t lds = (size_t)half * (12 + 16);
+  if (lds > 64 * 1024) return SONO_ERR_ARG;
+  const uint64_t want = (nframes + 3) / 4;
+  const uint32_t grid = (uint32_t)(want < (uint64_t)device_cu_count() * 8 ? want : (uint64_t)device_cu_count() * 8);
+  hipLaunchKernelGGL(filterbank_index_kernel, dim3(grid ? grid : 1), dim3(256), lds, reinterpret_cast<hipStream_t>(hip_stream), mags,
+                     nframes, half, fb_bin, w0, w1, bin_lo, bin_hi, out_bins, out_bin0, col0, fs, (float)((double)n / 2.0), out);
+  return hipGetLastError() == hipSuccess ? SONO_OK : SONO_ERR_DEVICE;
 }
 
 }  // namespace sono

@@ -110,6 +110,13 @@ uint64_t fast_rgba_scratch_bytes();
 int launch_pcm_to_f32(const void* src, uint32_t format_tag, uint32_t bits, uint32_t channels, uint32_t channel, uint64_t frames,
                       float* dst, void* hip_stream);
 uint64_t launch_valu_peak(float* sink, uint32_t iterations, void* hip_stream);
+// kernels_post.hip: the filter bank of a non-linear frequency scale (applyFilterBank, spectrogram.esm.js:479-488) over a
+// [frame][half] plane of float32 magnitudes, then the plugin quantiser: colour indices of the bins [bin_lo, bin_hi) into
+// out[(col0 + frame) * out_bins + bin - out_bin0].
+struct FastScale;
+int launch_filterbank_index(const float* mags, uint64_t nframes, uint32_t half, const int32_t* fb_bin, const double* w0, const double* w1,
+                            uint32_t bin_lo, uint32_t bin_hi, uint32_t out_bins, uint32_t out_bin0, uint64_t col0, const FastScale& fs,
+                            uint32_t n, uint8_t* out, void* hip_stream);
 int launch_frame_peaks(const uint8_t* idx, uint64_t frames, uint32_t bins, int32_t* peak_bin, uint8_t* peak_idx,
                        void* hip_stream);
 

@@ -650,6 +650,49 @@ def test_plugin_scaled_get_frequencies(case):
     assert np.array_equal(oracle.plugin_get_frequencies_scaled(x, case["N"], case["noverlap"], case["scale"], sr).shape, ref.shape)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,hop", [(1024, 256), (512, 128), (2048, 512), (4096, 1024)])
+@pytest.mark.parametrize("scale", ["mel", "logarithmic"])
+def test_scaled_frequencies_stay_on_the_float32_kernels(n, hop, scale):
+    """A non-linear frequency scale in the float32 arithmetic: magnitudes from the fast transform kernels, then the
+    filter-bank kernel; the general kernel is not involved.  Indices within 1 LSB of the checker's, the image is the
+    colour map applied to the same arithmetic's indices (any band), and a NaN sample turns every bin of the frames it
+    touches into index 0."""
+    rng = np.random.default_rng(n + 5)
+    sr = 256000
+    L = n + hop * 400 + 9
+    x = (rng.standard_normal(L) * 0.1).astype(np.float32)
+    t = np.arange(L, dtype=np.float64)
+    x += (0.6 * np.sin(t * 0.4 + 2e-6 * t * t) * (t > 3000)).astype(np.float32)
+    ref = oracle.plugin_get_frequencies_scaled(x, n, n - hop, scale, sr)
+    fb = E.filterbank_table(scale, n, sr)
+    with plugin_engine(n, hop, F.ARITH_FAST_F32) as eng:
+        eng.set_filterbank(*fb)
+        got = eng.stft(x)
+        route = eng.kernel_route()
+    assert "general" not in route and "filterbank_index_kernel" in route, route
+    d = cyc_diff(got, ref)
+    assert got.shape == ref.shape and d.max() <= 1 and (d != 0).mean() < 0.02, (d.max(), (d != 0).mean())
+    lut = (np.arange(1024, dtype=np.uint32) * 5 % 256).astype(np.uint8)
+    lo, hi = 3, n // 2 - 9
+    with plugin_engine(n, hop, F.ARITH_FAST_F32, out_kind=F.OUT_RGBA8, bin_lo=lo, bin_hi=hi) as eng:
+        eng.set_filterbank(*fb)
+        eng.set_colormap(lut)
+        img = eng.stft(x)
+        route = eng.kernel_route()
+    assert "general" not in route and "colorize_kernel" in route, route
+    assert np.array_equal(img, lut.reshape(256, 4)[got[:, lo:hi].T[::-1]])
+    xn = x.copy()
+    xn[n + 5 * hop + 17] = np.nan
+    with plugin_engine(n, hop, F.ARITH_FAST_F32) as eng:
+        eng.set_filterbank(*fb)
+        gn = eng.stft(xn)
+    s0 = n + 5 * hop + 17
+    hit = np.array([f * hop <= s0 < f * hop + n for f in range(len(gn))])
+    assert hit.sum() == n // hop and (gn[hit] == 0).all()
+    assert np.array_equal(gn[~hit], got[~hit])
+
+
 # ------------------------------------------------------------------ the canvas step of drawSpectrogram (:357-381)
 @pytest.mark.gpu
 @pytest.mark.parametrize("case", G.cases("plugin_render"), ids=lambda c: c["id"])

@@ -51,6 +51,19 @@ int main(int argc, char** argv) {
     fprintf(stderr, "sono_create: %s\n", sono_create_error());
     return 1;
   }
+  if (argc > 10) {  // a non-linear frequency scale: mel | logarithmic | bark | erb
+    const char* names[] = {"linear", "mel", "logarithmic", "bark", "erb"};
+    int which = -1;
+    for (int i = 1; i < 5; i++)
+      if (!strcmp(argv[10], names[i])) which = i;
+    std::vector<int32_t> tap(fft / 2);
+    std::vector<double> w0(fft / 2), w1(fft / 2);
+    if (which < 0 || sono_filterbank_table((uint32_t)which, fft, 384000.0, fft / 2, tap.data(), w0.data(), w1.data()) != SONO_OK ||
+        sono_set_filterbank(c, tap.data(), w0.data(), w1.data()) != SONO_OK) {
+      fprintf(stderr, "filter bank '%s': %s\n", argv[10], sono_last_error(c));
+      return 1;
+    }
+  }
   const uint64_t ob = sono_out_bytes(c, L);
   void* dx = sono_device_malloc(c, L * 4);
   void* dout = sono_device_malloc(c, ob);
