@@ -159,7 +159,10 @@ def main():
             cfg = dict(window_id=E.window_id("hann"), scale_mode=F.SCALE_PLUGIN_DB, frame_rule=F.FRAMES_PLUGIN_STRICT,
                        twiddle_mode=F.TW_PLUGIN_RECURRENCE, gain_db=20.0, range_db=80.0)
         arith = F.ARITH_EXACT_F64 if kw.pop("exact", False) else F.ARITH_FAST_F32
+        freq_scale = kw.pop("freq_scale", None)
         eng = E.Engine(fft_n=fft_n, hop=hop, arith=arith, out_kind=out_kind, device=local_rank, **cfg, **kw)
+        if freq_scale:            # the plugin's option scale: 'mel' | 'logarithmic' | 'bark' | 'erb' (spectrogram.esm.js:389-411)
+            eng.set_filterbank(*E.filterbank_table(freq_scale, fft_n, SAMPLE_RATE))
         eng.set_stream(torch.cuda.current_stream().cuda_stream)
         return eng
 
@@ -320,6 +323,7 @@ def main():
             ("rgba" if args.out == "u8" else "u8") + "_worker_1024": dict(out=("rgba" if args.out == "u8" else "u8")),
             "u8_plugin_getFrequencies_1024": dict(out="u8", path="plugin"),
             "features_plugin_1024": dict(out="features", path="plugin"),
+            "u8_plugin_mel_1024": dict(out="u8", path="plugin", freq_scale="mel"),
             "u8_worker_512_hop128": dict(out="u8", fft_n=512, hop=128),
             "rgba_worker_512_hop128": dict(out="rgba", fft_n=512, hop=128),      # the page's default FFT size (main.js:886-889)
             "features_plugin_512_hop128": dict(out="features", path="plugin", fft_n=512, hop=128),

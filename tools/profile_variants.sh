@@ -27,6 +27,7 @@ run worker_rgba_512 600 5 rgba 512 128 worker
 run worker_rgba_2048 600 5 rgba 2048 512 worker
 run plugin_rgba_2048 600 5 rgba 2048 512 plugin
 run plugin_u8_1024_exact 120 3 u8 1024 256 plugin 0 0 exact
+run plugin_u8_1024_mel 600 5 u8 1024 256 plugin 0 0 fast mel
 run worker_rgba_1024_exact 120 3 rgba 1024 256 worker 0 0 exact
 rm -f "$OUT"/*.log
 ls "$OUT"
