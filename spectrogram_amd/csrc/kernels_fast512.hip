@@ -22,7 +22,8 @@
 #include "sono_device.h"
 #include "sono_internal.h"
 #include "sono_launch.h"
-#include "sono_rgba_flush.h"
+#include "sono_fft32.h"
+#include "sono_image_ring.h"
 
 namespace sono {
 namespace fast512 {
@@ -147,7 +148,8 @@ __device__ __forceinline__ uint32_t put_index(float msq, const FastScale& fs, ui
 
 // Windowed samples (frames A0, A1 as re/im of registers 0..15, B0, B1 of 16..31; lane l = samples 32a + l) to the
 // two spectra: register k2 = Z_g[k1 + 16*k2] in lane 16g + k1.
-template <bool TABLE>
+// BLK: the transpose goes through the lane's 16 x 16 block (`plane`; sono_fft32.h) instead of a 32 x 32 plane.
+template <bool TABLE, bool BLK = false>
 __device__ __forceinline__ void transform512(float (&re)[32], float (&im)[32], const float2* tw_lds,
                                              const float2* __restrict__ tw_flat, float* plane, int l) {
   if constexpr (TABLE) {
@@ -165,6 +167,10 @@ __device__ __forceinline__ void transform512(float (&re)[32], float (&im)[32], c
     }
   }
   // transpose lane l, register r -> lane r, register l; the planes go through one buffer one after the other
+  if constexpr (BLK) {
+    fast1024::transpose32_plane(re, plane, l & 15);
+    fast1024::transpose32_plane(im, plane, l & 15);
+  } else {
 #pragma unroll
   for (int r = 0; r < 32; ++r) plane[r * kPlaneStride + l] = re[r];
   wave_sync();
@@ -189,6 +195,7 @@ __device__ __forceinline__ void transform512(float (&re)[32], float (&im)[32], c
     }
   }
   wave_sync();
+  }
   if constexpr (TABLE) {
     int kt = l & 15;
     asm volatile("" : "+v"(kt));  // (keeps the 31 factor addresses out of registers across the loop)
@@ -386,29 +393,40 @@ __global__ __launch_bounds__(kWaves * 64) void stft512_kernel(StftParams p, Fast
 }
 
 // RGBA: the image [row = row_of_bin0 - bin][column = col0 + frame] of LUT colours instead of [frame][bin] indices,
-// with the slot mechanism of the 1024-point kernel (sono_rgba_flush.h): a workgroup round is 256 consecutive frames =
-// two iterations (a wavefront takes 8 frames per iteration: frame groups 32i + 2*wave + h); the lane that reads the
-// bin quad 32P + l of both transforms already holds four bins x four frames, one 16-byte slot store; one barrier per
-// round; during the next round the first eight wavefronts (256 bins = 8 x 32 image rows) write the finished round
-// out, two quarters per iteration.  The samples of an iteration and the slot reads of its quarters are issued at
-// the end of the iteration before, so that the only wait on the memory counter comes before the image stores.
-// At the end of the recording a block of four frames is shifted back (loads stay in bounds) and the lane moves
-// the frames it owns to the front of its slot cell.
-#ifndef SONO_RF512
-#define SONO_RF512 256
-#endif
-constexpr int kRF = SONO_RF512;     // frames per workgroup round: 256 (two iterations) or 128 (one, a barrier per iteration: measured no faster)
+// with the workgroup's exchange of colour indices in LDS and whole-sector stores (sono_image_ring.h), arranged like the
+// 1024-point image writer (kernels_fast_rgba.hip):
+//   * a round is 256 consecutive frames = two iterations (a wavefront takes 8 frames per iteration, a half-wavefront 4 of
+//     them: frame group 32*iteration + 2*wave + h); a workgroup owns a contiguous range of rounds;
+//   * the transposes go through 16 x 16 blocks (4.25 KiB per wavefront), and the epilogue pairs Z[k] with Z[512 - k] in
+//     four passes of 64 bins, each 16-lane row (one transform) in its own block; after an even and an odd pass
+//     v_permlane16_swap trades between the two transforms of a half-wavefront, so that a lane holds four bins x four
+//     frames: bin quad 32m + 16g + k1 in lane (g, k1);
+//   * one ring slot (256 bin rows x 272 frames), two barriers per round, both between iterations: iteration 0 writes out
+//     the parts 0, 1 of the round before (wavefront w owns the 16 rows of bins 16w .. 16w+15; a part is 4 rows; a lane
+//     stores 16 bytes of a row's 1-KiB run), transforms, keeps its epilogue's indices in registers and reads the parts
+//     2, 3; iteration 1: barrier, writes out the parts 2, 3, transforms, stores both epilogues' indices into the slot,
+//     barrier, reads the parts 0, 1 of the new round.
+// At the end of the recording a block of four frames is shifted back (loads stay in bounds) and the lane moves the
+// frames it owns to the front of its cell.
+constexpr int kRF = 256;            // frames per workgroup round
 constexpr int kRIters = kRF / 128;  // iterations per round
-constexpr int kFPI = 4 / kRIters;   // quarters written out per iteration
+constexpr int kWaveBytes = 4 * fast1024::kBlkFloats * 4;  // 4352
+constexpr int kBlkBytes = fast1024::kBlkFloats * 4;       // 1088: a 16-lane row's block; epilogue pass: 64 values + 65 partners
+static_assert((64 + 65) * 8 <= kBlkBytes, "an epilogue pass must fit the row's block");
+constexpr int kLutBytes = 1024;
+constexpr int kOffWave = kTwBytes + kWinBytes + kLutBytes;
+constexpr int kOffSlot = kOffWave + kWaves * kWaveBytes;
+constexpr int kRgbaLdsBytes = kOffSlot + image_ring::Ring<kRF>::bytes(256);
+static_assert(kRgbaLdsBytes <= 160 * 1024, "LDS of one CU");
 
 template <bool PLUGIN, typename In, int HOP32, bool TABLE>
-__global__ __launch_bounds__(kWaves * 64) void stft512_rgba_kernel(StftParams p, FastScale fs, const float2* __restrict__ tw_table,
-                                                                   uint8_t* __restrict__ tiles) {
-  using rgba_flush::kRoundBytes;
+__global__ __launch_bounds__(kWaves * 64) void stft512_rgba_kernel(StftParams p, FastScale fs, const float2* __restrict__ tw_table) {
+  using namespace image_ring;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float2* tw_lds = reinterpret_cast<float2*>(smem);
   float* win_lds = reinterpret_cast<float*>(smem + kTwBytes);
-  uint32_t* lut_lds = reinterpret_cast<uint32_t*>(smem + kLdsBytes);
+  uint32_t* lut_lds = reinterpret_cast<uint32_t*>(smem + kTwBytes + kWinBytes);
+  uint32_t* slot = reinterpret_cast<uint32_t*>(smem + kOffSlot);
   const float2* __restrict__ tw_flat = reinterpret_cast<const float2*>(p.twiddles);
   for (int i = threadIdx.x; i < 512; i += kWaves * 64) {
     if constexpr (TABLE) {
@@ -429,23 +447,22 @@ __global__ __launch_bounds__(kWaves * 64) void stft512_rgba_kernel(StftParams p,
 
   const int lane = threadIdx.x & 63, l = lane & 31, h = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  unsigned char* fbuf = smem + kTwBytes + kWinBytes + (wave * 2 + h) * kFftBufBytes;
-  float* plane = reinterpret_cast<float*>(fbuf);
-  float2* cell = reinterpret_cast<float2*>(fbuf);
+  unsigned char* wbuf = smem + kOffWave + wave * kWaveBytes;
+  float* blk = reinterpret_cast<float*>(wbuf + (lane >> 4) * kBlkBytes);  // this 16-lane row's block: transposes, then epilogue
   const float4* win_row = reinterpret_cast<const float4*>(win_lds + l * kWinStride);
   const In* __restrict__ x = reinterpret_cast<const In*>(p.pcm);
   const uint32_t per = gridDim.x >> 3;
   const uint32_t vb = (gridDim.x & 7) ? blockIdx.x : (blockIdx.x & 7) * per + (blockIdx.x >> 3);
-  uint32_t* slots = reinterpret_cast<uint32_t*>(tiles + (size_t)blockIdx.x * 2 * kRoundBytes);
-  // every workgroup runs the same number of rounds and every wavefront goes through every round (barriers)
+  // every workgroup runs the same number of rounds and every wavefront goes through every round (barriers); a workgroup's
+  // rounds are consecutive frames
   const uint64_t nrounds = (p.nframes + kRF - 1) / kRF;
   const uint64_t rounds = (nrounds + gridDim.x - 1) / gridDim.x;
+  const Range rg = make_range<kRF>(p, vb, rounds);
 
   // first frame of this half-wavefront in iteration `it` (>= nframes: nothing of its own)
   auto first_frame = [&](uint64_t it) -> uint64_t {
-    const uint64_t round = it / kRIters;
-    if (round >= rounds) return p.nframes;
-    return (round * gridDim.x + vb) * kRF + 128 * (it % kRIters) + 8 * wave + 4 * h;
+    if (it >= rounds * kRIters) return p.nframes;
+    return rg.f_lo + 128 * it + 8 * wave + 4 * h;
   };
   constexpr int kRaw = HOP32 > 0 ? 16 + 3 * HOP32 : 64;
   float raw[kRaw];
@@ -466,26 +483,46 @@ __global__ __launch_bounds__(kWaves * 64) void stft512_rgba_kernel(StftParams p,
       }
     }
   };
+  // this lane's four frames of each of the four rows of the parts `first_part`, +1 of round k: wavefront w owns the rows of
+  // bins 16w .. 16w+15, lane j the frames 256k - e + 4j .. +3
+  auto read_rows = [&](uint32_t (&fq)[2][4], int first_part, uint64_t k) {
+    int w = wave, j = lane;
+    asm volatile("" : "+s"(w));
+    asm volatile("" : "+v"(j));
+#pragma unroll
+    for (int q = 0; q < 2; ++q) read4<kRF>(slot, p, rg, fq[q], 16 * w + 4 * (first_part + q), j, k);
+  };
+  auto flush_rows = [&](const uint32_t (&d)[4], uint64_t fround, int part) {
+    int w = wave, j = lane;
+    asm volatile("" : "+s"(w));   // (loop-invariant addresses computed in place: hoisted, they would hold registers the
+    asm volatile("" : "+v"(j));   //  transforms need)
+    const int bin0 = 16 * w + 4 * part;
+    if (bin0 + 4 <= (int)p.bin_lo || bin0 >= (int)p.bin_hi) return;
+    flush4<kRF>(p, rg, d, lut_lds, fround, bin0, j, bin0 >= (int)p.bin_lo && bin0 + 4 <= (int)p.bin_hi);
+  };
+
   fetch(first_frame(0));
-  uint4 fq[kFPI][2] = {};  // slot reads of the quarters the iteration writes out
-  for (uint64_t it = 0; it < (rounds + 1) * kRIters; ++it) {
+  uint32_t fq[2][4] = {};    // indices of the two parts the next iteration writes out
+  uint32_t pend[2][4] = {};  // indices of iteration 0's epilogue, stored into the slot in iteration 1
+  bool pend_active = false;
+  for (uint64_t it = 0; it < (rounds + 2) * kRIters; ++it) {
     const uint64_t round = it / kRIters;
-    const int i = (int)(it % kRIters);
+    const int sub = (int)(it % kRIters);
     const uint64_t f0 = first_frame(it);
-    uint32_t* slot = slots + (round & 1) * (kRoundBytes / 4);
+    // iteration 1: every wavefront has read its parts 2, 3 of the round before (end of its iteration 0), so the slot may
+    // be overwritten from here on
+    if (sub == 1) __syncthreads();
     // (the empty asm is a use of the loaded registers: the wait for them lands here, before the image stores)
 #pragma unroll
     for (int a = 0; a < kRaw; ++a) asm volatile("" : "+v"(raw[a]));
-    if (round > 0) {
-      const uint64_t frame0 = ((round - 1) * gridDim.x + vb) * kRF;
-      if (frame0 < p.nframes) {
-#pragma unroll
-        for (int j = 0; j < kFPI; ++j) rgba_flush::flush_quarter_store<kRF>(p, fq[j], lut_lds, frame0, kFPI * i + j, wave, lane);
-      }
+    if (round > 0 && rg.f_lo < rg.f_hi) {
+      const uint64_t fround = rg.f_lo + (round - 1) * kRF;
+      flush_rows(fq[0], fround, 2 * sub);
+      flush_rows(fq[1], fround, 2 * sub + 1);
     }
     // wave-uniform: does this wavefront have a frame in this iteration?
-    const uint64_t wave_f0 = round < rounds ? (round * gridDim.x + vb) * kRF + 128 * i + 8 * wave : p.nframes;
-    if (wave_f0 < p.nframes) {
+    const bool active = it < rounds * kRIters && rg.f_lo + 128 * it + 8 * wave < p.nframes;
+    if (active) {
       float re[32], im[32];
       {
         float win[16];
@@ -502,29 +539,35 @@ __global__ __launch_bounds__(kWaves * 64) void stft512_rgba_kernel(StftParams p,
           im[16 + brev4(a)] = raw[a + (HOP32 > 0 ? 3 * HOP32 : 48)] * win[a];
         }
       }
-      transform512<TABLE>(re, im, tw_lds, tw_flat, plane, l);
+      transform512<TABLE, true>(re, im, tw_lds, tw_flat, blk, l);  // register k2 = Z_g[k1 + 16*k2] in lane 16g + k1
 
       int lane_e = lane;
       asm volatile("" : "+v"(lane_e));  // (keeps loop-invariant addresses out of registers the transforms need)
-      const int le = lane_e & 31, he = lane_e >> 5;
-      // frames of this lane's slot cell: f0 .. f0+3; the block computed is fb = f0 - shift .. (shift > 0 at the end)
+      const int ke = lane_e & 15, ge = (lane_e >> 4) & 1, he = lane_e >> 5;
+      // frames of this lane's cell: f0 .. f0+3; the block computed is fb = f0 - shift .. (shift > 0 at the end)
       const uint64_t fb = f0 + 4 <= p.nframes ? f0 : p.nframes - 4;
       const int shift = f0 >= p.nframes ? 4 : (int)(f0 - fb);
-      const int fg = 32 * i + 2 * wave + he;
+      const int fg = 32 * sub + 2 * wave + he;
+      // Epilogue in four passes of 64 bins, each row (transform) in its own block: values Z[64P + j] at cell j, partners
+      // Z[512 - 64P - j] at cell 64 + j (j <= 64).  The values are the registers 4P..4P+3 (j = k1 + 16r), the partners the
+      // registers 28-4P..31-4P (j = 64 - k1 - 16r); the partner of j = 0 is one register off: Z[(512 - 64P) mod 512],
+      // register (32 - 4P) mod 32 of lane k1 = 0.  A lane reads the bins 64P + 4*k1 .. +3 of its transform.
+      float2* cz = reinterpret_cast<float2*>(blk);
+      uint32_t wa2[2], wb2[2];
 #pragma unroll
-      for (int P = 0; P < 2; ++P) {
-        epilogue_cells(P, re, im, cell, le);
+      for (int P = 0; P < 4; ++P) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          cz[ke + 16 * r] = make_float2(re[4 * P + r], im[4 * P + r]);
+          cz[64 + 64 - ke - 16 * r] = make_float2(re[28 - 4 * P + r], im[28 - 4 * P + r]);
+        }
+        if (ke == 0) cz[64] = make_float2(re[(32 - 4 * P) & 31], im[(32 - 4 * P) & 31]);
         wave_sync();
-        uint32_t w4[4];  // colour indices of bins 128P + 4le .. +3 of the frames fb, fb+1 (transform 0), fb+2, fb+3 (transform 1)
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-          const float2* lr = cell + q * 128 + 4 * le;
-          const float2* mr = cell + kMirrorBase + q * kMirrorStride + 4 * le;
-          const float4 z01 = *reinterpret_cast<const float4*>(lr);
-          const float4 z23 = *reinterpret_cast<const float4*>(lr + 2);
-          const float4 q01 = *reinterpret_cast<const float4*>(mr);
-          const float4 q23 = *reinterpret_cast<const float4*>(mr + 2);
-          uint32_t wa = 0, wb = 0;
+        const float4 z01 = *reinterpret_cast<const float4*>(cz + 4 * ke);
+        const float4 z23 = *reinterpret_cast<const float4*>(cz + 4 * ke + 2);
+        const float4 q01 = *reinterpret_cast<const float4*>(cz + 64 + 4 * ke);
+        const float4 q23 = *reinterpret_cast<const float4*>(cz + 64 + 4 * ke + 2);
+        uint32_t wa = 0, wb = 0;
 #define SONO_BIN(B, ZR, ZI, PR, PI)                                          \
   {                                                                          \
     const float ar = (ZR) + (PR), ai = (ZI) - (PI);                          \
@@ -532,34 +575,54 @@ __global__ __launch_bounds__(kWaves * 64) void stft512_rgba_kernel(StftParams p,
     wa = put_index<PLUGIN, B>(__builtin_fmaf(ar, ar, ai * ai), fs, wa);      \
     wb = put_index<PLUGIN, B>(__builtin_fmaf(br, br, bi * bi), fs, wb);      \
   }
-          SONO_BIN(0, z01.x, z01.y, q01.x, q01.y)
-          SONO_BIN(1, z01.z, z01.w, q01.z, q01.w)
-          SONO_BIN(2, z23.x, z23.y, q23.x, q23.y)
-          SONO_BIN(3, z23.z, z23.w, q23.z, q23.w)
+        SONO_BIN(0, z01.x, z01.y, q01.x, q01.y)
+        SONO_BIN(1, z01.z, z01.w, q01.z, q01.w)
+        SONO_BIN(2, z23.x, z23.y, q23.x, q23.y)
+        SONO_BIN(3, z23.z, z23.w, q23.z, q23.w)
 #undef SONO_BIN
-          w4[2 * q] = wa;
-          w4[2 * q + 1] = wb;
+        wa2[P & 1] = wa;
+        wb2[P & 1] = wb;
+        wave_sync();  // the block is rewritten by the next pass / the next iteration's transpose
+        if (P & 1) {
+          // before: the lanes of transform g hold the frames (fb + 2g, +1) of the bin quads 32m + k1 (even pass) and
+          // 32m + 16 + k1 (odd pass); after: lane (g, k1) holds the quad 32m + 16g + k1 of all four frames
+          const auto sa = __builtin_amdgcn_permlane16_swap(wa2[0], wa2[1], false, false);
+          const auto sb = __builtin_amdgcn_permlane16_swap(wb2[0], wb2[1], false, false);
+          uint32_t w4[4] = {sa[0], sb[0], sa[1], sb[1]};
+          if (shift != 0) {  // the frames this lane owns start at position `shift` of the block
+            const uint32_t c1 = w4[1], c2 = w4[2], c3 = w4[3];
+            w4[0] = shift == 1 ? c1 : shift == 2 ? c2 : c3;
+            w4[1] = shift == 1 ? c2 : c3;
+            w4[2] = c3;
+          }
+          const int kq = 32 * (P >> 1) + 16 * ge + ke;
+          if (sub == 0) {
+            turn(w4[0], w4[1], w4[2], w4[3], pend[P >> 1]);
+          } else {
+            uint32_t r4[4];
+            turn(w4[0], w4[1], w4[2], w4[3], r4);
+            park<kRF>(slot, p, r4, round, fg, kq);
+          }
         }
-        if (shift != 0) {  // the frames this lane owns start at position `shift` of the block
-          const uint32_t c1 = w4[1], c2 = w4[2], c3 = w4[3];
-          w4[0] = shift == 1 ? c1 : shift == 2 ? c2 : c3;
-          w4[1] = shift == 1 ? c2 : c3;
-          w4[2] = c3;
-        }
-        const int kq = 32 * P + le;
-        if (4 * kq + 3 >= (int)p.bin_lo && 4 * kq < (int)p.bin_hi)
-          reinterpret_cast<uint4*>(slot)[rgba_flush::slot_cell<kRF>(kq, fg)] = make_uint4(w4[0], w4[1], w4[2], w4[3]);
-        wave_sync();  // the buffer is rewritten by the next half / the next iteration's transpose
       }
     }
-    fetch(first_frame(it + 1));  // unconditional: a half with nothing of its own reads the last block of the recording
-    if (i == kRIters - 1) __syncthreads();  // this round's slot is complete and everyone is done reading the other one
-    const uint64_t nround = (it + 1) / kRIters;
-    if (nround > 0 && nround <= rounds) {
-      const uint32_t* prev = slots + ((nround - 1) & 1) * (kRoundBytes / 4);
-      const int ni = (int)((it + 1) % kRIters);
+    if (sub == 0) {
+      pend_active = active;
+    } else if (pend_active) {  // frame group 2*wave + h of the round: the indices iteration 0 kept
+      int lane_e = lane;
+      asm volatile("" : "+v"(lane_e));
 #pragma unroll
-      for (int j = 0; j < kFPI; ++j) rgba_flush::flush_quarter_load<kRF>(fq[j], prev, kFPI * ni + j, wave, lane);
+      for (int m = 0; m < 2; ++m) park<kRF>(slot, p, pend[m], round, 2 * wave + (lane_e >> 5), 32 * m + (lane_e & 31));
+    }
+    fetch(first_frame(it + 1));  // unconditional: a half with nothing of its own reads the last block of the recording
+    if (sub == 0) {
+      // the slot still holds the round before: take the last two parts of this wavefront's 16 rows
+      if (round > 0) read_rows(fq, 2, round - 1);
+    } else {
+      // the round's slot is complete once every wavefront is here; then take the first two parts (after the last round:
+      // of the empty round that only has the frames the last one left behind)
+      __syncthreads();
+      if (round <= rounds) read_rows(fq, 0, round);
     }
   }
 }
@@ -587,8 +650,7 @@ bool fast512_available(const StftParams& p) {
   return !(p.out_bins & 3) && !(p.out_bin0 & 3) && !(reinterpret_cast<uintptr_t>(p.out) & 3);
 }
 
-// The image output needs the flipped full-height row mapping, a LUT and the scratch buffer
-// (fast_rgba_scratch_bytes()).
+// The image output needs the flipped full-height row mapping and a LUT (any band; no scratch buffer).
 bool fast512_rgba_available(const StftParams& p) {
   if (p.n != 512 || p.nframes < 8) return false;
   if (!((p.fast_mode == 1 && p.fast_table) || (p.fast_mode == 2 && p.twiddles))) return false;
@@ -601,7 +663,7 @@ bool fast512_rgba_available(const StftParams& p) {
 int launch_stft_fast512(const StftParams& p, void* stream_v) {
   using namespace fast512;
   const bool rgba = p.out_kind == SONO_OUT_RGBA8;
-  if (rgba ? !(fast512_rgba_available(p) && p.tile_scratch) : !fast512_available(p)) return 1;
+  if (rgba ? !fast512_rgba_available(p) || (reinterpret_cast<uintptr_t>(p.out) & 3) : !fast512_available(p)) return 1;
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_v);
   FastScale fs = make_fast_scale(p.scale_mode, p.n, p.gain_db, p.range_db);
   fs.b -= 2.0f * fs.a;  // the pair separation leaves 2*X: |2X|^2 = 4|X|^2
@@ -616,13 +678,12 @@ int launch_stft_fast512(const StftParams& p, void* stream_v) {
   if (rgba) {
     const uint64_t nr = (p.nframes + kRF - 1) / kRF;
     const uint32_t rgrid = (uint32_t)(nr < (uint64_t)cus ? nr : (uint64_t)cus);
-    uint8_t* tiles = reinterpret_cast<uint8_t*>(p.tile_scratch);
-    const int lds = kLdsBytes + rgba_flush::kLutBytes;
+    const int lds = kRgbaLdsBytes;
 #define SONO_R512(PL, In, H, T)                                                                                 \
   do {                                                                                                          \
     auto kern = stft512_rgba_kernel<PL, In, H, T>;                                                              \
     SONO_GRANT_LDS(kern, lds);                                                                                  \
-    hipLaunchKernelGGL(kern, dim3(rgrid), dim3(kWaves * 64), lds, stream, p, fs, table, tiles);                 \
+    hipLaunchKernelGGL(kern, dim3(rgrid), dim3(kWaves * 64), lds, stream, p, fs, table);                        \
   } while (0)
 #define SONO_R512_H(PL, In)                                                                                    \
   do {                                                                                                         \

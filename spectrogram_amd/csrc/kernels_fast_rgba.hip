@@ -15,16 +15,8 @@
 //   * the epilogue pairs Z[k] with Z[N-k] in quarters of 128 bins (2 KiB per transform).
 // LDS: 8 KiB twiddle matrix + 4.5 KiB window + 1 KiB colour map + 16 x 4.25 KiB + 74 KiB slot = 155.5 KiB.
 //
-// Whole 64-byte sectors only.  The image's row pitch (4 x width bytes) is no multiple of 64 bytes, so a 512-byte run
-// that starts at a round boundary straddles sector boundaries at both ends, and the two halves of such a sector come
-// from different rounds at different times: written with the runs cut at the round boundaries, the same image takes
-// 4.2 ms to store (stores alone, no transform); cut at sector boundaries 2.9 ms.  So a workgroup owns a CONTIGUOUS
-// range of frames, and the run of a row in a round starts `e` frames before the round, e = 0..15 chosen per row so
-// that the run starts on a sector boundary: the last e indices of the round before are still in the slot.  The slot
-// is one ring of 144 frames per bin row (36 dwords of four frames each, byte = frame): round k occupies dwords
-// 32k .. 32k+31 (mod 36), which leaves the last 16 frames of round k-1 in place.  A lane reads two neighbouring dwords
-// of its row and v_alignbyte_b32 cuts the four frames it stores out of them.  Partial sectors remain only where the
-// ranges of two workgroups meet (each masks the frames that are not its own) and at the ends of the recording.
+// Whole 64-byte sectors only: the slot is the ring of sono_image_ring.h (a workgroup owns a contiguous range of frames,
+// a row's run starts e = 0..15 frames before the round so that it starts on a sector boundary).
 //
 // One slot, two barriers per round, both between iterations.  Iteration 0 of round k+1: write out quarters 0, 1 of
 // round k (read at the end of round k), transform, keep the epilogue's indices in registers, read quarters 2, 3 of
@@ -36,6 +28,7 @@
 
 #include "sono_device.h"
 #include "sono_fft32.h"
+#include "sono_image_ring.h"
 #include "sono_internal.h"
 #include "sono_launch.h"
 
@@ -43,6 +36,7 @@ namespace sono {
 namespace fast1024r {
 
 using namespace fast1024;
+using namespace image_ring;
 
 constexpr int kWaves = 16;
 constexpr int kRoundFrames = 128;
@@ -62,77 +56,21 @@ constexpr int kPlane1 = 512 + 64;
 constexpr int kMirrorOffset = kPlane1 + 512;
 static_assert(2 * kMirrorOffset <= kQuarterBytes, "an epilogue quarter must fit half the wavefront's slice");
 __device__ __forceinline__ int quarter_pos(int j) { return ((j >> 1) & 1) * kPlane1 + (j >> 2) * 16 + (j & 1) * 8; }
-constexpr int kRingDwords = 36;                      // per bin row: 144 frames, four per dword
-constexpr int kRowPitch = 37;                        // dwords per bin row (odd: the stores of a bin quad's rows spread over banks)
-constexpr int kSlotBytes = 512 * kRowPitch * 4;
+constexpr int kSlotBytes = Ring<kRoundFrames>::bytes(512);
 constexpr int kOffWin = kTwBytes, kOffLut = kOffWin + kWinBytes, kOffWave = kOffLut + kLutBytes, kOffSlot = kOffWave + kWaves * kWaveBytes;
 constexpr int kLdsBytes = kOffSlot + kSlotBytes;
 static_assert(kLdsBytes <= 160 * 1024, "LDS budget");
 
-typedef uint32_t u32x4_unaligned __attribute__((ext_vector_type(4), aligned(4)));
-
-// What the image writer needs to know about the workgroup's range of frames.
-struct Range {
-  uint64_t f_lo, f_hi;  // frames [f_lo, f_hi) are this workgroup's
-  uint32_t align_px;    // (address of pixel (row 0, frame f_lo) / 4) mod 16
-};
-
-// The run of bin row `bin` starts e = 0..15 frames before a round, so that it starts on a 64-byte boundary.
-__device__ __forceinline__ int row_lead(const StftParams& p, const Range& rg, int bin) {
-  const uint32_t row = (uint32_t)(p.row_of_bin0 - bin);
-  return (int)((rg.align_px + (row & 15u) * ((uint32_t)p.width & 15u)) & 15u);
-}
-
 // Image rows of one quarter (`part` 0..3) of the round that starts at frame `fround`: wavefront `wave` owns bins
 // 32*wave .. +31 and writes the eight rows of bins 32*wave + 8*part .. +7; lane j stores four pixels (16 bytes) of the rows
-// 4*(j & 1) + i, i = 0..3, of the quarter: frames fround - e + 4*(j >> 1) .. +3; 32 lanes form the 512-byte run of a row.
-// d[i] holds those four frames' indices, byte t = frame + t (read_rows).
+// 4*(j & 1) + i, i = 0..3, of the quarter: 32 lanes form the 512-byte run of a row.
 __device__ __forceinline__ void flush_rows(const StftParams& p, const Range& rg, const uint32_t (&d)[4], const uint32_t* lut_lds,
                                            uint64_t fround, int part, int wave, int lane) {
   asm volatile("" : "+s"(wave));   // (everything below is loop-invariant; computed in place it costs a few instructions,
   asm volatile("" : "+v"(lane));   //  hoisted it would hold registers the transforms need)
-  const int qsel = lane & 1, fsel = lane >> 1;
-  const int64_t width4 = (int64_t)p.width * 4;
   const int bin0 = 32 * wave + 8 * part;
   if (bin0 + 8 <= (int)p.bin_lo || bin0 >= (int)p.bin_hi) return;
-  const int binq = bin0 + 4 * qsel;
-  uint8_t* __restrict__ base = reinterpret_cast<uint8_t*>(p.out) + (int64_t)(p.col0 + fround) * 4 +
-                               (int64_t)(p.row_of_bin0 - binq) * width4 + 16 * fsel;
-  // e of consecutive rows differs by the width (mod 16)
-  const uint32_t wstep = (uint32_t)p.width & 15u;
-  uint32_t e = (uint32_t)row_lead(p, rg, binq);
-  // wave-uniform: every row of the quarter is in the band and every frame it writes is this workgroup's
-  const bool plain = bin0 >= (int)p.bin_lo && bin0 + 8 <= (int)p.bin_hi && fround >= rg.f_lo + 16 && fround + kRoundFrames <= rg.f_hi;
-  if (plain) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const uint32_t v = d[i];
-      u32x4_unaligned px;
-      px.x = lut_lds[v & 255u];
-      px.y = lut_lds[(v >> 8) & 255u];
-      px.z = lut_lds[(v >> 16) & 255u];
-      px.w = lut_lds[v >> 24];
-      *reinterpret_cast<u32x4_unaligned*>(base - (int64_t)i * width4 - 4 * (int)e) = px;
-      e = (e - wstep) & 15u;  // the next bin is one row up
-    }
-    return;
-  }
-  // (frames relative to the start of the range: an image is at most 2^24 columns wide)
-  const int rel0 = (int)(fround - rg.f_lo) + 4 * fsel, span = (int)(rg.f_hi - rg.f_lo);
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const uint32_t ei = e;
-    e = (e - wstep) & 15u;
-    if (binq + i < (int)p.bin_lo || binq + i >= (int)p.bin_hi) continue;
-    const uint32_t v = d[i];
-    const uint32_t px[4] = {lut_lds[v & 255u], lut_lds[(v >> 8) & 255u], lut_lds[(v >> 16) & 255u], lut_lds[v >> 24]};
-    uint32_t* o = reinterpret_cast<uint32_t*>(base - (int64_t)i * width4 - 4 * (int)ei);
-    const int f = rel0 - (int)ei;
-    // where the range begins or ends: only the frames that are this workgroup's
-#pragma unroll
-    for (int t = 0; t < 4; ++t)
-      if (f + t >= 0 && f + t < span) o[t] = px[t];
-  }
+  flush4<kRoundFrames>(p, rg, d, lut_lds, fround, bin0 + 4 * (lane & 1), lane >> 1, bin0 >= (int)p.bin_lo && bin0 + 8 <= (int)p.bin_hi);
 }
 
 // HOP32 > 0: hop == 32*HOP32 and one run of 32 + HOP32 loads feeds both frames of a pair; 0: any hop, two runs of 32.
@@ -181,11 +119,7 @@ __global__ __launch_bounds__(kWaves * 64, 4) void stft1024_rgba_kernel(StftParam
   // frames of its own), because the rounds are fenced by workgroup barriers; a workgroup's rounds are consecutive frames
   const uint64_t nrounds = (p.nframes + kRoundFrames - 1) / kRoundFrames;
   const uint64_t rounds = (nrounds + gridDim.x - 1) / gridDim.x;
-  Range rg;
-  rg.f_lo = (uint64_t)vb * rounds * kRoundFrames;
-  rg.f_hi = rg.f_lo + rounds * kRoundFrames < p.nframes ? rg.f_lo + rounds * kRoundFrames : p.nframes;
-  if (rg.f_hi < rg.f_lo) rg.f_hi = rg.f_lo;
-  rg.align_px = (uint32_t)((reinterpret_cast<uintptr_t>(p.out) >> 2) + p.col0 + rg.f_lo) & 15u;
+  const Range rg = make_range<kRoundFrames>(p, vb, rounds);
 
   struct Unit {
     uint64_t f0;
@@ -235,49 +169,13 @@ __global__ __launch_bounds__(kWaves * 64, 4) void stft1024_rgba_kernel(StftParam
     }
   };
   // this lane's four frames of each of its rows, for the two quarters the next iteration writes out of round k (of this
-  // workgroup): row 4*(j & 1) + i of the quarter, frames 128k - e + 4*(j >> 1) .. +3, cut out of two neighbouring ring dwords
+  // workgroup): row 4*(j & 1) + i of the quarter
   auto read_rows = [&](uint32_t (&fq)[2][4], int first_part, uint64_t k) {
     int w = wave, j = lane;
     asm volatile("" : "+s"(w));
     asm volatile("" : "+v"(j));
-    const int ringpos = (int)((32 * k) % kRingDwords);  // first dword of round k
-    const uint32_t wstep = (uint32_t)p.width & 15u;
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      uint32_t e = (uint32_t)row_lead(p, rg, 32 * w + 8 * (first_part + q) + 4 * (j & 1));
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int bin = 32 * w + 8 * (first_part + q) + 4 * (j & 1) + i;
-        int d0 = ringpos + (j >> 1) - (int)((e + 3) >> 2);  // -4 .. 66
-        const uint32_t shift = (0u - e) & 3u;
-        e = (e - wstep) & 15u;                               // the next bin is one row up
-        d0 += d0 < 0 ? kRingDwords : 0;
-        d0 -= d0 >= kRingDwords ? kRingDwords : 0;
-        int d1 = d0 + 1;
-        d1 -= d1 >= kRingDwords ? kRingDwords : 0;
-        const uint32_t* row = slot + bin * kRowPitch;
-        fq[q][i] = __builtin_amdgcn_alignbyte(row[d1], row[d0], shift);  // byte t = frame + t
-      }
-    }
-  };
-  // The indices of four frames x four bins as the epilogue leaves them (word = frame, byte = bin) turned into word = bin,
-  // byte = frame: what the ring rows hold.
-  auto turn = [](uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3, uint32_t (&r)[4]) {
-    const uint32_t t0 = __builtin_amdgcn_perm(w1, w0, 0x05010400u), t1 = __builtin_amdgcn_perm(w1, w0, 0x07030602u);
-    const uint32_t t2 = __builtin_amdgcn_perm(w3, w2, 0x05010400u), t3 = __builtin_amdgcn_perm(w3, w2, 0x07030602u);
-    r[0] = __builtin_amdgcn_perm(t2, t0, 0x05040100u);
-    r[1] = __builtin_amdgcn_perm(t2, t0, 0x07060302u);
-    r[2] = __builtin_amdgcn_perm(t3, t1, 0x05040100u);
-    r[3] = __builtin_amdgcn_perm(t3, t1, 0x07060302u);
-  };
-  // frame group fg (0..31) of round k, bin quad kq: one dword into each of the quad's four rows
-  auto park = [&](const uint32_t (&r)[4], uint64_t k, int fg, int kq) {
-    if (4 * kq + 3 < (int)p.bin_lo || 4 * kq >= (int)p.bin_hi) return;
-    int d = (int)((32 * k) % kRingDwords) + fg;
-    d -= d >= kRingDwords ? kRingDwords : 0;
-    uint32_t* row = slot + 4 * kq * kRowPitch + d;
-#pragma unroll
-    for (int b = 0; b < 4; ++b) row[b * kRowPitch] = r[b];
+    for (int q = 0; q < 2; ++q) read4<kRoundFrames>(slot, p, rg, fq[q], 32 * w + 8 * (first_part + q) + 4 * (j & 1), j >> 1, k);
   };
 
   Unit cur = locate(0);
@@ -393,7 +291,7 @@ __global__ __launch_bounds__(kWaves * 64, 4) void stft1024_rgba_kernel(StftParam
           } else {
             uint32_t r4[4];
             turn(sa[0], sb[0], sa[1], sb[1], r4);
-            park(r4, round, kWaves + wave, 32 * (Q - 1) + l + 32 * h);
+            park<kRoundFrames>(slot, p, r4, round, kWaves + wave, 32 * (Q - 1) + l + 32 * h);
           }
         }
       }
@@ -402,7 +300,7 @@ __global__ __launch_bounds__(kWaves * 64, 4) void stft1024_rgba_kernel(StftParam
       pend_active = cur.active;
     } else if (pend_active) {  // frame group `wave` of the round: the cells iteration 0 kept
 #pragma unroll
-      for (int P = 0; P < 2; ++P) park(pend[P], round, wave, 64 * P + l + 32 * h);
+      for (int P = 0; P < 2; ++P) park<kRoundFrames>(slot, p, pend[P], round, wave, 64 * P + l + 32 * h);
     }
     fetch(nxt);  // unconditional (an inactive unit points at frame 0): no stale values carried round the loop
     cur = nxt;

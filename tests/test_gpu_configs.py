@@ -110,21 +110,22 @@ def test_fft4096_kernel_indices_and_image(hop, in_kind, round_frames, monkeypatc
             assert img.shape == want.shape and np.array_equal(img, want)
 
 
-def test_image_writer_sector_alignment_cases():
-    """The 1024-point image writer cuts every row's runs at 64-byte boundaries of the output, which depend on the
+@pytest.mark.parametrize("n", [1024, 512])
+def test_image_writer_sector_alignment_cases(n):
+    """The 1024- and 512-point image writers cut every row's runs at 64-byte boundaries of the output, which depend on the
     output address, the image width and the row: images of every width residue mod 16 (the pitch in pixels), written at
     every 4-byte offset inside a sector, with enough frames for several rounds per workgroup's neighbour and a band that
     is not a whole number of quads, must equal the colour map applied to the [frame][bin] indices of the same arithmetic;
     nothing may be written outside the image."""
     rng = np.random.default_rng(64)
     lut = (np.arange(1024, dtype=np.uint32) * 13 % 256).astype(np.uint8)
-    hop, n = 256, 1024
+    hop, rf, H = n // 4, 128 * 1024 // n, n // 2     # frames per round: 128 at 1024 points, 256 at 512
     # (rounds per workgroup: one in the small cases, so that every run ends at a range boundary; four in the large ones,
     # so that most runs take the unmasked path)
-    for case, (extra, off_px, lo, hi, rounds) in enumerate([(0, 0, 0, 512, 9), (1, 1, 0, 512, 9), (5, 7, 26, 342, 9), (9, 15, 0, 512, 9),
-                                                            (14, 3, 100, 101, 9), (3, 8, 0, 512, 9), (11, 13, 4, 508, 9),
-                                                            (7, 5, 0, 512, 1024 - 3), (10, 11, 30, 335, 1024 - 50)]):
-        frames = rounds * 128 + 40 + extra          # widths of different residues mod 16
+    for case, (extra, off_px, lo, hi, rounds) in enumerate([(0, 0, 0, H, 9), (1, 1, 0, H, 9), (5, 7, 26, H - 170, 9), (9, 15, 0, H, 9),
+                                                            (14, 3, 100, 101, 9), (3, 8, 0, H, 9), (11, 13, 4, H - 4, 9),
+                                                            (7, 5, 0, H, 1024 - 3), (10, 11, 30, H - 177, 1024 - 50)]):
+        frames = rounds * rf + 40 + extra           # widths of different residues mod 16
         L = n + hop * (frames - 1) + 1 + (hop - 2 if case % 2 else 0)
         x = (rng.standard_normal(L) * 0.2).astype(np.float32)
         with worker_engine(n, hop, out_kind=F.OUT_U8_INDEX) as eng:
@@ -141,7 +142,7 @@ def test_image_writer_sector_alignment_cases():
                 guard = np.full(need + 2 * pad, 0xA5, np.uint8)
                 eng.copy_to_device(d_out, guard)
                 eng.stft_device(d_in, len(x), d_out + pad + 4 * off_px, need)
-                assert eng.kernel_route().startswith("stft1024_rgba_kernel"), eng.kernel_route()
+                assert eng.kernel_route().startswith("stft%d_rgba_kernel" % n), eng.kernel_route()
                 got = np.empty(need + 2 * pad, np.uint8)
                 eng.copy_to_host(got, d_out)
             finally:
