@@ -243,7 +243,12 @@ __global__ __launch_bounds__(kMaxWaves * 64, 4) void stft1024_u8_kernel(StftPara
     // k1 -> lane k1, register l; the real and the imaginary plane go through the same LDS buffer one
     // after the other
     if constexpr (TABLE) {
-      fft32_table<true>(re, im, [&](int half, int j) { return tw_lds[31 * 32 + half - 1 + j]; });  // stages T = 1..16, wave-uniform
+      // stages T = 1..16: wave-uniform factors, read by scalar loads (the table is not written while the kernel runs;
+      // the opaque copy keeps the 62 scalars from being held in registers round the frame loop)
+      typedef const float __attribute__((address_space(4))) * const_table;
+      const_table twc = (const_table)(uintptr_t)tw_flat;
+      asm volatile("" : "+s"(twc));
+      fft32_table<true>(re, im, [&](int half, int j) { return make_float2(twc[2 * (half - 1 + j)], twc[2 * (half - 1 + j) + 1]); });
     } else {
       fft32(re, im);  // Y_l[k1]
 #pragma unroll

@@ -181,7 +181,12 @@ __device__ __forceinline__ void transform2048(float (&re)[32], float (&im)[32], 
                                               float* plane, int lane) {
   const int k1r = lane & 31, hb = lane >> 5;
   if constexpr (TABLE) {
-    fft32_table<true>(re, im, [&](int half, int j) { return tw_lds[63 * 32 + half - 1 + j]; });
+    // stages T = 1..16: wave-uniform factors by scalar loads (the table is not written while the kernel runs; the opaque
+    // copy keeps the scalars from being held in registers round the frame loop)
+    typedef const float __attribute__((address_space(4))) * const_table;
+    const_table twc = (const_table)(uintptr_t)tw_flat;
+    asm volatile("" : "+s"(twc));
+    fft32_table<true>(re, im, [&](int half, int j) { return make_float2(twc[2 * (half - 1 + j)], twc[2 * (half - 1 + j) + 1]); });
   } else {
     fft32(re, im);  // Y_l[k1]
 #pragma unroll

@@ -83,9 +83,15 @@ __device__ __forceinline__ float4 ld4<int16_t>(const int16_t* p) {
 // The complex 2048-point transform of one wavefront with the factors of the reference's network.  In: lane (v, u),
 // register brev5(a) = z[64a + 2v + u], i.e. the lane's registers are the positions 32 * (32u + brev5(v)) + r of the
 // bit-reversed order.  Out: register m of lane k1 + 32 hb = Z[k1 + 32m + 1024hb].
-__device__ __forceinline__ void transform2048(float (&re)[32], float (&im)[32], const float2* tw_lds, float* blk, int lane) {
+__device__ __forceinline__ void transform2048(float (&re)[32], float (&im)[32], const float2* tw_lds, const float2* tw_flat, float* blk,
+                                              int lane) {
   const int k1r = lane & 31, hb = lane >> 5;
-  fft32_table<true>(re, im, [&](int half, int j) { return tw_lds[63 * 32 + half - 1 + j]; });  // stages T = 1..16
+  // stages T = 1..16: wave-uniform factors by scalar loads (the table is not written while the kernel runs; the opaque
+  // copy keeps the scalars from being held in registers round the frame loop)
+  typedef const float __attribute__((address_space(4))) * const_table;
+  const_table twc = (const_table)(uintptr_t)tw_flat;
+  asm volatile("" : "+s"(twc));
+  fft32_table<true>(re, im, [&](int half, int j) { return make_float2(twc[2 * (half - 1 + j)], twc[2 * (half - 1 + j) + 1]); });
   // lane (v, u), register k1 -> lane (k1, u), register brev5(v): position 32 * (32u + m) + k1 in register m
   transpose32_plane(re, blk, lane & 15);
   transpose32_plane(im, blk, lane & 15);
@@ -255,7 +261,7 @@ __global__ __launch_bounds__(kWaves * 64) void stft4096_kernel(StftParams p, Fas
       }
       int lt = lane;
       asm volatile("" : "+v"(lt));  // (keeps the transform's loop-invariant LDS addresses out of registers it needs itself)
-      transform2048(re, im, tw_lds, blk, lt);
+      transform2048(re, im, tw_lds, tw_flat, blk, lt);
 
       int le = lane;
       asm volatile("" : "+v"(le));

@@ -153,7 +153,12 @@ template <bool TABLE, bool BLK = false>
 __device__ __forceinline__ void transform512(float (&re)[32], float (&im)[32], const float2* tw_lds,
                                              const float2* __restrict__ tw_flat, float* plane, int l) {
   if constexpr (TABLE) {
-    dit32_table<4, true>(re, im, [&](int half, int j) { return tw_lds[31 * 16 + half - 1 + j]; });  // stages T = 1..8, wave-uniform
+    // stages T = 1..8: wave-uniform factors by scalar loads (the table is not written while the kernel runs; the opaque
+    // copy keeps the scalars from being held in registers round the frame loop)
+    typedef const float __attribute__((address_space(4))) * const_table;
+    const_table twc = (const_table)(uintptr_t)tw_flat;
+    asm volatile("" : "+s"(twc));
+    dit32_table<4, true>(re, im, [&](int half, int j) { return make_float2(twc[2 * (half - 1 + j)], twc[2 * (half - 1 + j) + 1]); });
   } else {
     dit32<4>(re, im);  // Y_l[k1] of A in registers k1, of B in 16 + k1
 #pragma unroll

@@ -216,7 +216,11 @@ __global__ __launch_bounds__(kWaves * 64, 4) void stft1024_rgba_kernel(StftParam
         }
       }
       if constexpr (TABLE) {
-        fft32_table<true>(re, im, [&](int half, int j) { return tw_lds[31 * 32 + half - 1 + j]; });  // stages T = 1..16
+        // stages T = 1..16: wave-uniform factors by scalar loads (see stft1024_u8_kernel)
+        typedef const float __attribute__((address_space(4))) * const_table;
+        const_table twc = (const_table)(uintptr_t)tw_flat;
+        asm volatile("" : "+s"(twc));
+        fft32_table<true>(re, im, [&](int half, int j) { return make_float2(twc[2 * (half - 1 + j)], twc[2 * (half - 1 + j) + 1]); });
       } else {
         fft32(re, im);  // Y_l[k1], then the twiddle W_1024^(l*k1)
 #pragma unroll
