@@ -101,12 +101,7 @@ __global__ __launch_bounds__(kMaxWaves * 64, 4) void stft1024_u8_kernel(StftPara
       if (r < 31) {
         const int half = 1 << (31 - __builtin_clz(r + 1)), j = r + 1 - half;
         tw_lds[i] = tw_flat[32 * half - 1 + 32 * j + lane_p];
-      } else if (lane_p < 31) {
-        // last row: the 31 factors of the first pass (stages T = 1..16, flat positions 0..30).  Read from LDS they
-        // cost a broadcast read each; read from global memory they would be vector loads (the compiler cannot
-        // prove them unclobbered) that wait behind the image stores on the same counter.
-        tw_lds[i] = tw_flat[lane_p];
-      }
+      }  // (the 31 factors of the first pass, flat positions 0..30, are wave-uniform and read by scalar loads)
     } else {
       tw_lds[i] = tw_table[i];
     }

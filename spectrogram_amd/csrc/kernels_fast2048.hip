@@ -332,9 +332,7 @@ __global__ __launch_bounds__(kWaves * 64) void stft2048_kernel(StftParams p, Fas
         tw_lds[i] = tw_flat[32 * t - 1 + 32 * j + k];
       } else if (r < 63) {
         tw_lds[i] = tw_flat[1023 + 32 * (r - 31) + k];
-      } else if (k < 31) {
-        tw_lds[i] = tw_flat[k];  // last row: the 31 factors of the first pass (broadcast reads instead of global loads)
-      }
+      }  // (the 31 factors of the first pass are read by scalar loads)
     } else {
       tw_lds[i] = tw_table[i];
     }
@@ -506,9 +504,7 @@ __global__ __launch_bounds__(kWaves * 64) void stft2048_rgba_kernel(StftParams p
         tw_lds[i] = tw_flat[32 * t - 1 + 32 * j + k];
       } else if (r < 63) {
         tw_lds[i] = tw_flat[1023 + 32 * (r - 31) + k];
-      } else if (k < 31) {
-        tw_lds[i] = tw_flat[k];  // last row: the 31 factors of the first pass (broadcast reads instead of global loads)
-      }
+      }  // (the 31 factors of the first pass are read by scalar loads)
     } else {
       tw_lds[i] = tw_table[i];
     }

@@ -157,9 +157,7 @@ __global__ __launch_bounds__(kWaves * 64) void stft4096_kernel(StftParams p, Fas
       tw_lds[i] = tw_flat[32 * t - 1 + 32 * j + k];
     } else if (r < 63) {
       tw_lds[i] = tw_flat[1023 + 32 * (r - 31) + k];
-    } else if (k < 31) {
-      tw_lds[i] = tw_flat[k];  // last row: the 31 factors of the stages T = 1..16
-    }
+    }  // (the 31 factors of the stages T = 1..16 are read by scalar loads)
     last_lds[(i >> 1 & 1) * 1024 + (i >> 2) * 2 + (i & 1)] = tw_flat[2047 + i];  // two planes, like an epilogue pass
     win_lds[i] = p.window[i];
     win_lds[2048 + i] = p.window[2048 + i];

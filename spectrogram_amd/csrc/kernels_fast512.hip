@@ -244,9 +244,7 @@ __global__ __launch_bounds__(kWaves * 64) void stft512_kernel(StftParams p, Fast
       if (r < 31) {
         const int t = 1 << (31 - __builtin_clz(r + 1)), j = r + 1 - t;
         tw_lds[i] = tw_flat[16 * t - 1 + 16 * j + kk];
-      } else if (kk < 15) {
-        tw_lds[i] = tw_flat[kk];  // last row: the 15 factors of the first pass (broadcast reads instead of global loads)
-      }
+      }  // (the 15 factors of the first pass are read by scalar loads)
     } else {
       tw_lds[i] = tw_table[i];
     }
@@ -439,9 +437,7 @@ __global__ __launch_bounds__(kWaves * 64) void stft512_rgba_kernel(StftParams p,
       if (r < 31) {
         const int t = 1 << (31 - __builtin_clz(r + 1)), j = r + 1 - t;
         tw_lds[i] = tw_flat[16 * t - 1 + 16 * j + kk];
-      } else if (kk < 15) {
-        tw_lds[i] = tw_flat[kk];  // last row: the 15 factors of the first pass (broadcast reads instead of global loads)
-      }
+      }  // (the 15 factors of the first pass are read by scalar loads)
     } else {
       tw_lds[i] = tw_table[i];
     }

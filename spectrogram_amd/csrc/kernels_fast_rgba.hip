@@ -91,9 +91,7 @@ __global__ __launch_bounds__(kWaves * 64, 4) void stft1024_rgba_kernel(StftParam
       if (r < 31) {
         const int half = 1 << (31 - __builtin_clz(r + 1)), j = r + 1 - half;
         tw_lds[i] = tw_flat[32 * half - 1 + 32 * j + lane_p];
-      } else if (lane_p < 31) {
-        tw_lds[i] = tw_flat[lane_p];  // last row: the 31 factors of the first pass (stages T = 1..16)
-      }
+      }  // (the 31 factors of the first pass are read by scalar loads)
     } else {
       tw_lds[i] = tw_table[i];
     }
