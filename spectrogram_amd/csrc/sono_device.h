@@ -49,21 +49,65 @@ __device__ __forceinline__ bool peak_outside(int kbest, uint32_t feat_lo, uint32
   return kbest < (int)feat_lo || kbest >= (int)feat_hi;
 }
 
+// Cross-lane moves of the peak reductions, all on the vector ALU (a shuffle through LDS costs an LDS round trip per
+// step, ten dependent ones per frame): lane ^ 1 and lane ^ 2 by DPP quad permutations, then rotations by 4 and 8 within
+// the row of 16 lanes (what a quad holds is uniform by then, so a rotation serves as well as an exchange), then
+// v_permlane16_swap / v_permlane32_swap, which hand a lane its own value in one result and the partner row's / half's in
+// the other.
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+template <int CTRL>
+__device__ __forceinline__ int dpp_i(int v) {
+  return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, false);
+}
+constexpr int kDppXor1 = 0xB1, kDppXor2 = 0x4E, kDppRor4 = 0x124, kDppRor8 = 0x128;
+
+// larger value wins, equal values go to the lower bin
+__device__ __forceinline__ void peak_merge(float& best, int& kbest, float o, int ko) {
+  const bool g = o > best || (o == best && ko < kbest);
+  best = g ? o : best;
+  kbest = g ? ko : kbest;
+}
+
+// Over the WIDTH (32 or 64) lanes of a transform: the largest value and its bin in every lane, and in `next` the
+// runner-up (the largest value of any other bin).
 template <int WIDTH>
 __device__ __forceinline__ void reduce_peak(float& best, int& kbest, float& next) {
   const float mine = best;
   const int kmine = kbest;
-#pragma unroll
-  for (int m = 1; m < WIDTH; m <<= 1) {
-    const float o = __shfl_xor(best, m, 64);
-    const int ko = __shfl_xor(kbest, m, 64);
-    const bool g = o > best || (o == best && ko < kbest);
-    best = g ? o : best;
-    kbest = g ? ko : kbest;
+  peak_merge(best, kbest, dpp_f<kDppXor1>(best), dpp_i<kDppXor1>(kbest));
+  peak_merge(best, kbest, dpp_f<kDppXor2>(best), dpp_i<kDppXor2>(kbest));
+  peak_merge(best, kbest, dpp_f<kDppRor4>(best), dpp_i<kDppRor4>(kbest));
+  peak_merge(best, kbest, dpp_f<kDppRor8>(best), dpp_i<kDppRor8>(kbest));
+  {
+    const auto b = __builtin_amdgcn_permlane16_swap(__float_as_uint(best), __float_as_uint(best), false, false);
+    const auto k = __builtin_amdgcn_permlane16_swap((uint32_t)kbest, (uint32_t)kbest, false, false);
+    best = __uint_as_float(b[0]);
+    kbest = (int)k[0];
+    peak_merge(best, kbest, __uint_as_float(b[1]), (int)k[1]);
+  }
+  if constexpr (WIDTH == 64) {
+    const auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(best), __float_as_uint(best), false, false);
+    const auto k = __builtin_amdgcn_permlane32_swap((uint32_t)kbest, (uint32_t)kbest, false, false);
+    best = __uint_as_float(b[0]);
+    kbest = (int)k[0];
+    peak_merge(best, kbest, __uint_as_float(b[1]), (int)k[1]);
   }
   float c = (kmine == kbest) ? next : mine;   // the winning lane offers its runner-up, every other lane its best
-#pragma unroll
-  for (int m = 1; m < WIDTH; m <<= 1) c = __builtin_fmaxf(c, __shfl_xor(c, m, 64));
+  c = __builtin_fmaxf(c, dpp_f<kDppXor1>(c));
+  c = __builtin_fmaxf(c, dpp_f<kDppXor2>(c));
+  c = __builtin_fmaxf(c, dpp_f<kDppRor4>(c));
+  c = __builtin_fmaxf(c, dpp_f<kDppRor8>(c));
+  {
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(c), __float_as_uint(c), false, false);
+    c = __builtin_fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+  }
+  if constexpr (WIDTH == 64) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(c), __float_as_uint(c), false, false);
+    c = __builtin_fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+  }
   next = c;
 }
 
