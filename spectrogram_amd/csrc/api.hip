@@ -611,8 +611,23 @@ static int launch_range(sono_ctx* c, const StftParams& q, const IndexScratch& au
     }
     return SONO_OK;
   }
-  const StftParams& fq = (ragged && q.out_kind == SONO_OUT_FEATURES) ? w : q;
+  StftParams fq = (ragged && q.out_kind == SONO_OUT_FEATURES) ? w : q;
+  // (1024 points: the float32 feature kernel lists the frames it marks itself, in the queue the fix-up pass reads)
+  bool listed = false;
+  if (fast && q.out_kind == SONO_OUT_FEATURES && q.n == 1024 && c->d_tw_exact && c->d_claim && fast_features_available(fq)) {
+    StftParams u = q;
+    u.twiddles = c->d_tw_exact;
+    u.tile_scratch = c->d_claim;
+    u.fixup = kFixupCapacity;
+    if (features_fixup_available(u)) {
+      HIP_TRY(c, hipMemsetAsync(c->d_claim, 0, 16, c->stream));
+      fq.feat_queue = reinterpret_cast<uint32_t*>(c->d_claim);
+      fq.feat_queue_cap = kFixupCapacity;
+      listed = true;
+    }
+  }
   if (fast) r = launch_stft_fast(fq, c->stream);
+  if (r != SONO_OK) listed = false;
   if (r == 1 && fast) r = launch_stft_fast512(fq, c->stream);
   if (r == 1 && fast) r = launch_stft_fast2048(fq, c->stream);
   if (r == 1 && fast) r = launch_stft_fast4096(fq, c->stream);
@@ -639,7 +654,7 @@ static int launch_range(sono_ctx* c, const StftParams& q, const IndexScratch& au
     u.twiddles = c->d_tw_exact;
     u.tile_scratch = c->d_claim;
     u.fixup = kFixupCapacity;
-    r = launch_features_fixup(u, c->stream);
+    r = launch_features_fixup(u, c->stream, listed);
     if (r == 1) {
       u.fixup = 1;
       HIP_TRY(c, hipMemsetAsync(c->d_claim, 0, 16, c->stream));

@@ -309,15 +309,18 @@ bool features_fixup_available(const StftParams& p) {
 
 uint64_t features_fixup_queue_bytes(uint32_t capacity) { return ((uint64_t)exact1024::kQueueHeader + capacity) * 4; }
 
-int launch_features_fixup(const StftParams& p, void* stream_v) {
+// `listed`: the float32 kernel has put the frames it marked into the queue itself (StftParams::feat_queue).
+int launch_features_fixup(const StftParams& p, void* stream_v, bool listed) {
   using namespace exact1024;
   if (!features_fixup_available(p)) return 1;
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_v);
-  if (hipMemsetAsync(p.tile_scratch, 0, kQueueHeader * 4, stream) != hipSuccess) return SONO_ERR_DEVICE;
-  const uint32_t per = kCompactThreads * kCompactPerThread;
-  hipLaunchKernelGGL(feature_marks_compact_kernel, dim3((uint32_t)((p.nframes + per - 1) / per)), dim3(kCompactThreads), 0, stream,
-                     reinterpret_cast<const sono_frame_feature*>(p.out) + p.col0, p.nframes, reinterpret_cast<uint32_t*>(p.tile_scratch),
-                     p.fixup);
+  if (!listed) {
+    if (hipMemsetAsync(p.tile_scratch, 0, kQueueHeader * 4, stream) != hipSuccess) return SONO_ERR_DEVICE;
+    const uint32_t per = kCompactThreads * kCompactPerThread;
+    hipLaunchKernelGGL(feature_marks_compact_kernel, dim3((uint32_t)((p.nframes + per - 1) / per)), dim3(kCompactThreads), 0, stream,
+                       reinterpret_cast<const sono_frame_feature*>(p.out) + p.col0, p.nframes,
+                       reinterpret_cast<uint32_t*>(p.tile_scratch), p.fixup);
+  }
   // the list's length is only known on the device: a full grid, whose wavefronts find their entries or none
   const uint64_t need = (p.nframes + kWaves * 2 - 1) / (kWaves * 2);
   const uint64_t cap = (uint64_t)device_cu_count();   // 192 registers: one workgroup (two wavefronts per SIMD) per CU

@@ -401,6 +401,10 @@ __global__ __launch_bounds__(kMaxWaves * 64, 4) void stft1024_u8_kernel(StftPara
           r.peak_idx = (uint8_t)put_index<PLUGIN, 0>(best_a, fs, 0);
           r.reserved[0] = (feature_uncertain(best_a, next_a, best_b, ta, fs) || peak_outside(kbest_a, p.feat_lo, p.feat_hi)) ? 1 : 0;
           ft[0] = r;
+          if (r.reserved[0] && p.feat_queue) {  // (a few frames per thousand)
+            const uint32_t at = atomicAdd(p.feat_queue, 1u);
+            if (at < p.feat_queue_cap) p.feat_queue[4 + at] = (uint32_t)f0;
+          }
         }
         if (st_b) {
           sono_frame_feature r{};
@@ -408,6 +412,10 @@ __global__ __launch_bounds__(kMaxWaves * 64, 4) void stft1024_u8_kernel(StftPara
           r.peak_idx = (uint8_t)put_index<PLUGIN, 0>(best_b, fs, 0);
           r.reserved[0] = (feature_uncertain(best_b, next_b, best_a, tb, fs) || peak_outside(kbest_b, p.feat_lo, p.feat_hi)) ? 1 : 0;
           ft[1] = r;
+          if (r.reserved[0] && p.feat_queue) {
+            const uint32_t at = atomicAdd(p.feat_queue, 1u);
+            if (at < p.feat_queue_cap) p.feat_queue[4 + at] = (uint32_t)f0 + 1;
+          }
         }
       }
     }

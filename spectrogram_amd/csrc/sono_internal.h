@@ -51,6 +51,10 @@ struct StftParams {
   uint32_t feat_lo, feat_hi;  // SONO_OUT_FEATURES from a float32 kernel: the band the records are for.  The kernels search whole
                           // groups of four bins ([bin_lo, bin_hi) is that band rounded outwards) and mark a record whose
                           // peak fell outside [feat_lo, feat_hi) for the exact-arithmetic pass, which searches the band itself
+  uint32_t* feat_queue;   // SONO_OUT_FEATURES from a float32 kernel that lists the records it marks itself (1024 points): the
+                          // fix-up queue (a header of 4 words, word 0 = number of marked records, then feat_queue_cap frame
+                          // numbers within the launch), or nullptr: the marks are collected from the records afterwards
+  uint32_t feat_queue_cap;
   uint32_t fixup;         // != 0: recompute only the feature records a float32 kernel marked (reserved[0] != 0); for
                           // launch_features_fixup the capacity of the queue's list
   double gain_db, range_db;
@@ -87,7 +91,7 @@ bool mw_u8_available(const StftParams& p);
 // kernels_exact.hip: recomputes, in the exact arithmetic, the records of a SONO_OUT_FEATURES output that a fast kernel
 // marked as too close to call (reserved[0] != 0) and clears the mark.  `p.twiddles` must be the double2 table.
 // `p.tile_scratch` is the pass's queue of features_fixup_queue_bytes(p.fixup) bytes, p.fixup the capacity of its list.
-int launch_features_fixup(const StftParams& p, void* hip_stream);
+int launch_features_fixup(const StftParams& p, void* hip_stream, bool listed = false);
 bool features_fixup_available(const StftParams& p);
 uint64_t features_fixup_queue_bytes(uint32_t capacity);
 // kernels_exact.hip: the exact arithmetic for 1024-point frames, two in-register passes (returns 1 if it does not
