@@ -419,7 +419,9 @@ static int refresh_routes(sono_ctx* c) {
   const bool ragged_u8 = c->cfg.out_kind == SONO_OUT_U8_INDEX && ((c->bin_lo | c->bin_hi) & 3u) && (c->fast_mode || c->mw_ok);
   const bool fb_route = (c->fb_fast_mode || c->fb_mw_ok) && (c->cfg.out_kind == SONO_OUT_RGBA8 || c->cfg.out_kind == SONO_OUT_U8_INDEX);
   if (c->cfg.out_kind == SONO_OUT_RGBA8 || ragged_u8 || fb_route) {
-    const uint64_t want = c->fast_mode && !ragged_u8 ? fast_rgba_scratch_bytes() : kDefaultChunkBytes;
+    // (the magnitude chunks of the filter-bank route are 4 bytes per bin: the largest chunk that still stays in the
+    // Infinity Cache keeps the transform kernel's launches long enough to fill the chip)
+    const uint64_t want = fb_route ? kMaxChunkBytes : c->fast_mode && !ragged_u8 ? fast_rgba_scratch_bytes() : kDefaultChunkBytes;
     if (c->d_aux_bytes < want) {
       HIP_TRY(c, hipStreamSynchronize(c->stream));
       int rc = ensure(c, &c->d_aux, &c->d_aux_bytes, want);
