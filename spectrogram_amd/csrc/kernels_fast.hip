@@ -46,50 +46,23 @@ static_assert(kMirrorOffset + 257 * 8 <= kFftBufBytes, "epilogue half must fit t
 constexpr int kTwBytes = 32 * 32 * 8;
 constexpr int kWinBytes = 32 * kPlaneStride * 4;   // window as [l][kPlaneStride]: lane l reads w[32a + l], a = 0..31, as 8 x 16 B
 constexpr int lds_bytes(int waves) { return kTwBytes + kWinBytes + waves * 2 * kFftBufBytes; }  // 16 waves: 160256
-// RGBA output: a workgroup round covers 128 consecutive frames (8 per wavefront, two iterations =
-// 32 frame groups of 4); their colour indices are parked in one of the workgroup's two slots of a
-// global scratch buffer as [reader wavefront 16][frame group 32][bin quad 8] x 16 bytes (four frames x
-// four bins), 64 KiB, which is meant to stay in L2 / Infinity Cache.  (SONO_RF = 256: rounds of 256 frames, 1-KiB row
-// runs instead of 512-byte ones; measured 2 % slower: a slot line lives twice as long between its write and its read.)
-#ifndef SONO_RF
-#define SONO_RF 128
-#endif
-constexpr int kRoundFrames = SONO_RF;
-constexpr int kTileFrames = kRoundFrames / 16;     // frames per wavefront and round
-using rgba_flush::kRoundBytes;
-using rgba_flush::kLutBytes;
-static_assert(kRoundFrames == kMaxWaves * kTileFrames, "a round is one tile per wavefront");
-
 // HOP32 > 0: hop == 32*HOP32, so frame B's sample 32a+l is frame A's sample 32(a+HOP32)+l and one
 // run of 32+HOP32 loads feeds both frames.  HOP32 == 0: any hop, two runs of 32 loads.
 //
-// RGBA: the output is the image [row = row_of_bin0 - bin][column = col0 + frame] of LUT colours
-// instead of [frame][bin] indices.  A frame is one image COLUMN, so writing frames as they are
-// finished would scatter 16-byte pieces over 512 rows; partial 64-byte sectors cost the memory a
-// read-modify-write, and a store instruction that touches many cache lines is slow in the CU.  So the
-// workgroup parks the indices of a round (kRoundFrames consecutive frames) in a scratch slot that stays in
-// cache, meets at ONE barrier per round, and during the next round every wavefront writes its 32
-// image rows of the finished round, two quarters (of eight rows) per iteration (flush_quarter), from the other slot.
-// The stores of a quarter are issued after the next iteration's sample loads, so neither waits for
-// the other.  The two half-wavefronts first swap registers (v_permlane32_swap) so that a lane holds
-// the same four bins of all four frames of the iteration: one 16-byte scratch store per lane and
-// epilogue half, 128 bytes (one line) per eight lanes.
-//
-// OUT: kOutU8 / kOutRgba / kOutFeatures (per-frame spectral peak: strict-> first-wins argmax of |X|^2
+// The image output is a kernel of its own (kernels_fast_rgba.hip).
+// OUT: kOutU8 / kOutFeatures (per-frame spectral peak: strict-> first-wins argmax of |X|^2
 // over the band and that bin's colour index; 8 bytes per frame).
 // TABLE: twiddles are the context's per-stage table (flat layout, stage with half size T at [T-1, 2T-1))
 // instead of exact roots of unity: the first pass reads its 31 factors as wave-uniform scalars, the
 // second pass reads factor 32*(g mod t) + lane of stage T = 32t from a [31][32] copy in LDS, and there
 // is no twiddle multiplication between the passes (it is part of those factors).
 // kOutDb / kOutMag: float32 20*log10(m) / m per bin, [frame][bin] (what the tolerance tests read).
-constexpr int kOutU8 = 0, kOutRgba = 1, kOutFeatures = 2, kOutDb = 3, kOutMag = 4;
+constexpr int kOutU8 = 0, kOutFeatures = 2, kOutDb = 3, kOutMag = 4;
 template <bool PLUGIN, typename In, int HOP32, int OUT, bool TABLE>
 __global__ __launch_bounds__(kMaxWaves * 64, 4) void stft1024_u8_kernel(StftParams p, FastScale fs,
-                                                                        const float2* __restrict__ tw_table,
-                                                                        uint8_t* __restrict__ tiles) {
-  constexpr bool RGBA = OUT == kOutRgba, FEAT = OUT == kOutFeatures, FLT = OUT == kOutDb || OUT == kOutMag;
+                                                                        const float2* __restrict__ tw_table) {
+  constexpr bool FEAT = OUT == kOutFeatures, FLT = OUT == kOutDb || OUT == kOutMag;
   constexpr int kThreads = kMaxWaves * 64, kWaves = kMaxWaves;
-  constexpr int kTileIters = RGBA ? kTileFrames / 4 : 1;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float2* tw_lds = reinterpret_cast<float2*>(smem);
   float* win_lds = reinterpret_cast<float*>(smem + kTwBytes);
@@ -106,10 +79,6 @@ __global__ __launch_bounds__(kMaxWaves * 64, 4) void stft1024_u8_kernel(StftPara
       tw_lds[i] = tw_table[i];
     }
     win_lds[(i & 31) * kPlaneStride + (i >> 5)] = p.window[i];  // sample n = 32a + l at [l][a]
-  }
-  uint32_t* lut_lds = reinterpret_cast<uint32_t*>(smem + lds_bytes(kMaxWaves));
-  if constexpr (RGBA) {
-    for (int i = threadIdx.x; i < 256; i += kThreads) lut_lds[i] = p.lut[i];
   }
   __syncthreads();
 
@@ -128,45 +97,35 @@ __global__ __launch_bounds__(kMaxWaves * 64, 4) void stft1024_u8_kernel(StftPara
   const uint32_t per = gridDim.x >> 3;
   const uint32_t vb = (gridDim.x & 7) ? blockIdx.x : (blockIdx.x & 7) * per + (blockIdx.x >> 3);
 
-  uint32_t* slots = reinterpret_cast<uint32_t*>(tiles + (size_t)blockIdx.x * 2 * kRoundBytes);
-  // RGBA: every workgroup of the grid runs the same number of rounds and every wavefront goes through
-  // every round (with or without frames of its own), because the round ends in workgroup barriers
-  const uint64_t ntiles = (p.nframes + kTileFrames - 1) / kTileFrames;
-  const uint64_t rounds = (ntiles + (uint64_t)gridDim.x * kWaves - 1) / ((uint64_t)gridDim.x * kWaves);
-
-  // Iteration `it` of this wavefront: unit = four consecutive frames (two per half-wavefront); a
-  // wavefront takes kTileIters consecutive units per round.  Frames (f0, f0+1) form the complex input;
-  // st_a / st_b say which of the two results are stored.  An odd last frame is computed as the second
-  // member of the pair before it (shifted).  Returns false when the wavefront has no frame left.
+  // Iteration `it` of this wavefront: unit = four consecutive frames (two per half-wavefront).  Frames (f0, f0+1) form
+  // the complex input; st_a / st_b say which of the two results are stored.  An odd last frame is computed as the
+  // second member of the pair before it.  `active` is false when the wavefront has no frame left.
   struct Unit {
     uint64_t f0;
-    bool active, st_a, st_b, shifted;
+    bool active, st_a, st_b;
   };
   auto locate = [&](uint64_t it) -> Unit {
     Unit u;
-    const uint64_t tile_id = ((it / kTileIters) * gridDim.x + vb) * kWaves + wave;
-    const uint64_t pair0 = (tile_id * kTileIters + it % kTileIters) * 2;
+    const uint64_t pair0 = ((it * gridDim.x + vb) * kWaves + wave) * 2;
     u.active = pair0 < npairs;  // wave-uniform
     if (!u.active) {            // nothing left: point at frame 0 so that the sample loads stay in bounds
       u.f0 = 0;
-      u.st_a = u.st_b = u.shifted = false;
+      u.st_a = u.st_b = false;
       return u;
     }
     const uint64_t pair = pair0 + h;
     u.f0 = 2 * pair;
     u.st_a = u.st_b = pair < npairs;
-    u.shifted = false;
     if (!u.st_a) {  // this half has no pair of its own: it repeats valid frames and stores nothing
       u.f0 = 2 * pair0 + 1 < p.nframes ? 2 * pair0 : 2 * pair0 - 1;
     } else if (u.f0 + 1 >= p.nframes) {
       u.f0 -= 1;
       u.st_a = false;
-      u.shifted = true;
     }
     return u;
   };
-  // The samples of an iteration are loaded one iteration ahead (into raw), so that their latency and,
-  // in RGBA rounds, the drain of the image stores issued in between overlap with the arithmetic.
+  // The samples of an iteration are loaded one iteration ahead (into raw), so that their latency overlaps with the
+  // arithmetic.
   constexpr int kRaw = HOP32 > 0 ? 32 + HOP32 : 64;
   float raw[kRaw];
   auto fetch = [&](const Unit& u) {
@@ -185,40 +144,10 @@ __global__ __launch_bounds__(kMaxWaves * 64, 4) void stft1024_u8_kernel(StftPara
   };
   Unit cur = locate(0);
   fetch(cur);
-  constexpr int kPPI = RGBA ? 4 / kTileIters : 1;  // quarters written out per iteration
-  uint4 fq[kPPI][2] = {};  // RGBA: this lane's slot reads for the quarters that the iteration writes out
-  // RGBA: one more round than there are frames for, which only writes out the last slot
-  for (uint64_t it = 0; !RGBA || it < (rounds + 1) * kTileIters; ++it) {
-    if (!RGBA && !cur.active) break;
-    uint32_t* slot = slots + ((it / kTileIters) & 1) * (kRoundBytes / 4);
+  for (uint64_t it = 0; cur.active; ++it) {
     const Unit nxt = locate(it + 1);
-    // RGBA: a quarter of the previous round, from the other slot.  Its stores are issued right after
-    // the iteration has consumed its sample loads, when nothing else is in flight, and then have the
-    // whole iteration to drain before the next wait on the memory counter.
-    auto flush_prev = [&]() {
-      if constexpr (RGBA) {
-        const uint64_t round = it / kTileIters;
-        if (round > 0) {
-          const uint64_t frame0 = ((round - 1) * gridDim.x + vb) * kRoundFrames;
-          if (frame0 < p.nframes) {
-#pragma unroll
-            for (int j = 0; j < kPPI; ++j)
-              rgba_flush::flush_quarter_store<kRoundFrames>(p, fq[j], lut_lds, frame0, (int)(it % kTileIters) * kPPI + j, wave, lane);
-          }
-        }
-      }
-    };
-    if constexpr (RGBA) {
-      // (the empty asm is a use of the sample registers: the wait for their loads lands here, before
-      // the stores, and not behind them)
-#pragma unroll
-      for (int a = 0; a < kRaw; ++a) asm volatile("" : "+v"(raw[a]));
-      flush_prev();
-    }
-    do {
-    if (!cur.active) break;
     const uint64_t f0 = cur.f0;
-    const bool st_a = cur.st_a, st_b = cur.st_b, shifted = cur.shifted;
+    const bool st_a = cur.st_a, st_b = cur.st_b;
 
     float re[32], im[32];
     {
@@ -313,7 +242,6 @@ __global__ __launch_bounds__(kMaxWaves * 64, 4) void stft1024_u8_kernel(StftPara
       }
       if (l == 0) mbuf[0] = make_float2(re[P ? 24 : 0], im[P ? 24 : 0]);
       wave_sync();
-      uint32_t wa2[2], wb2[2];
 #pragma unroll
       for (int g = 0; g < 2; ++g) {
         const int idx = 4 * (lq + 32 * g);
@@ -359,10 +287,7 @@ __global__ __launch_bounds__(kMaxWaves * 64, 4) void stft1024_u8_kernel(StftPara
             }
           }
         }
-        if constexpr (RGBA) {
-          wa2[g] = shifted ? wb : wa;  // an odd last frame was computed as B: it belongs in the A slot
-          wb2[g] = wb;
-        } else if (FLT) {
+        if constexpr (FLT) {
           if (in_band) {
             float* o = reinterpret_cast<float*>(p.out) + (k - p.out_bin0);
             if (st_a) *reinterpret_cast<float4*>(o + row_a) = make_float4(fa[0], fa[1], fa[2], fa[3]);
@@ -373,16 +298,6 @@ __global__ __launch_bounds__(kMaxWaves * 64, 4) void stft1024_u8_kernel(StftPara
           if (st_a) *reinterpret_cast<uint32_t*>(out + row_a + col) = wa;
           if (st_b) *reinterpret_cast<uint32_t*>(out + row_b + col) = wb;
         }
-      }
-      if constexpr (RGBA) {
-        // before: lanes of half h hold frames (2h, 2h+1) of the iteration for the bin quads l (g = 0) and
-        // 32 + l (g = 1); after: lane (l, h) holds the quad l + 32h of all four frames
-        const auto sa = __builtin_amdgcn_permlane32_swap(wa2[0], wa2[1], false, false);
-        const auto sb = __builtin_amdgcn_permlane32_swap(wb2[0], wb2[1], false, false);
-        const int kq = 64 * P + l + 32 * h;               // reader wavefront kq >> 3, its quad kq & 7
-        const int fg = kTileIters * wave + (int)(it % kTileIters);  // frame group of the round
-        if (4 * kq + 3 >= (int)p.bin_lo && 4 * kq < (int)p.bin_hi)
-          reinterpret_cast<uint4*>(slot)[rgba_flush::slot_cell<kRoundFrames>(kq, fg)] = make_uint4(sa[0], sb[0], sa[1], sb[1]);
       }
       wave_sync();  // the buffer is rewritten by the next half / the next iteration's transpose
     }
@@ -419,21 +334,8 @@ __global__ __launch_bounds__(kMaxWaves * 64, 4) void stft1024_u8_kernel(StftPara
         }
       }
     }
-    } while (0);
     fetch(nxt);  // unconditional (an inactive unit points at frame 0): no stale values carried round the loop
     cur = nxt;
-    if constexpr (RGBA) {
-      // End of a round: this round's slot is complete (and visible: one CU, one L1), and every
-      // wavefront is done reading the other slot, which the next round overwrites.
-      if (it % kTileIters == kTileIters - 1) __syncthreads();
-      const uint64_t nround = (it + 1) / kTileIters;
-      if (nround > 0 && nround <= rounds) {
-#pragma unroll
-        for (int j = 0; j < kPPI; ++j)
-          rgba_flush::flush_quarter_load<kRoundFrames>(fq[j], slots + ((nround - 1) & 1) * (kRoundBytes / 4),
-                                                       (int)((it + 1) % kTileIters) * kPPI + j, wave, lane);
-      }
-    }
   }
 }
 
@@ -486,8 +388,9 @@ bool fast_rgba_available(const StftParams& p) {
   return true;
 }
 
-// two slots per workgroup; a slot of the 2048-point kernel (1024 bins x 256 frames) is twice that of the others
-uint64_t fast_rgba_scratch_bytes() { return (uint64_t)device_cu_count() * 2 * 2 * fast1024::kRoundBytes; }
+// Scratch of the image writers that exchange colour indices through global memory (2048 and 4096 points): two slots
+// per workgroup, a slot of the 2048-point kernel being 1024 bins x 256 frames.
+uint64_t fast_rgba_scratch_bytes() { return (uint64_t)device_cu_count() * 2 * 2 * rgba_flush::kRoundBytes; }
 
 int launch_stft_fast(const StftParams& p, void* stream_v) {
   using namespace fast1024;
@@ -495,11 +398,7 @@ int launch_stft_fast(const StftParams& p, void* stream_v) {
   const bool flt = p.out_kind == SONO_OUT_F32_DB || p.out_kind == SONO_OUT_F32_MAG;
   if (rgba) {
     if (!fast_rgba_available(p)) return 1;
-    // the image writer that keeps its exchange in LDS (kernels_fast_rgba.hip); SONO_RGBA_GLOBAL_SLOTS=1 selects the
-    // older one below, which parks the indices in a global scratch buffer (kept for comparison runs)
-    static const bool global_slots = getenv("SONO_RGBA_GLOBAL_SLOTS") != nullptr;
-    if (!global_slots) return launch_stft_fast_rgba(p, stream_v);
-    if (!p.tile_scratch) return 1;
+    return launch_stft_fast_rgba(p, stream_v);  // the image writer is a kernel of its own (kernels_fast_rgba.hip)
   } else if (flt) {
     if (!fast_float_available(p)) return 1;
     if (p.fast_mode == 2 && !p.pair_exact) return 1;  // two frames per transform: see StftParams::pair_exact
@@ -516,20 +415,18 @@ int launch_stft_fast(const StftParams& p, void* stream_v) {
   fs.db_off -= 2.0f * 3.0102999566f;
   fs.xtalk = (float)p.pair_asym;
   const uint64_t npairs = (p.nframes + 1) / 2;
-  // one wavefront handles 2 pairs per iteration, or (RGBA) one 16-frame tile per 4 iterations
-  const uint64_t per_wg = rgba ? (uint64_t)kRoundFrames / 2 : (uint64_t)kMaxWaves * 2;
+  const uint64_t per_wg = (uint64_t)kMaxWaves * 2;  // one wavefront handles 2 pairs per iteration
   const uint64_t need = (npairs + per_wg - 1) / per_wg;
   const int cus = device_cu_count();
   const uint32_t grid = (uint32_t)(need < (uint64_t)cus ? need : (uint64_t)cus);  // persistent: one workgroup per CU
   const float2* table = reinterpret_cast<const float2*>(p.fast_table);
-  uint8_t* tiles = reinterpret_cast<uint8_t*>(p.tile_scratch);
-  const int lds_total = lds_bytes(kMaxWaves) + (rgba ? kLutBytes : 0);
+  const int lds_total = lds_bytes(kMaxWaves);
   const bool tab = p.fast_mode == 2;
 #define SONO_LAUNCH_T(PLUGIN, In, H, O, T)                                                                  \
   do {                                                                                                      \
     auto kern = stft1024_u8_kernel<PLUGIN, In, H, O, T>;                                                    \
     SONO_GRANT_LDS(kern, lds_total);                                                                        \
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(kMaxWaves * 64), lds_total, stream, p, fs, table, tiles);     \
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kMaxWaves * 64), lds_total, stream, p, fs, table);            \
   } while (0)
 #define SONO_LAUNCH_O(PLUGIN, In, H, O)                                                                     \
   do {                                                                                                      \
@@ -537,8 +434,7 @@ int launch_stft_fast(const StftParams& p, void* stream_v) {
   } while (0)
 #define SONO_LAUNCH_H(PLUGIN, In, H)                                                                        \
   do {                                                                                                      \
-    if (rgba) SONO_LAUNCH_O(PLUGIN, In, H, kOutRgba);                                                       \
-    else if (feat) SONO_LAUNCH_O(PLUGIN, In, H, kOutFeatures);                                              \
+    if (feat) SONO_LAUNCH_O(PLUGIN, In, H, kOutFeatures);                                              \
     else if (p.out_kind == SONO_OUT_F32_DB) SONO_LAUNCH_O(PLUGIN, In, H, kOutDb);                           \
     else if (p.out_kind == SONO_OUT_F32_MAG) SONO_LAUNCH_O(PLUGIN, In, H, kOutMag);                         \
     else SONO_LAUNCH_O(PLUGIN, In, H, kOutU8);                                                              \

@@ -46,7 +46,7 @@ struct StftParams {
   const int32_t* fb_bin;  // device: non-linear frequency scale, first tap of output bin i (n/2 entries), or nullptr = linear
   const double* fb_w0;    // device: weight of bin fb_bin[i]
   const double* fb_w1;    // device: weight of bin fb_bin[i] + 1
-  void* tile_scratch;     // device: fast_rgba_scratch_bytes() of scratch for the fused RGBA output, or nullptr
+  void* tile_scratch;     // device: fast_rgba_scratch_bytes() of scratch for the 2048/4096-point image writers, or nullptr
   uint32_t scale_mode, out_kind, in_kind;
   uint32_t feat_lo, feat_hi;  // SONO_OUT_FEATURES from a float32 kernel: the band the records are for.  The kernels search whole
                           // groups of four bins ([bin_lo, bin_hi) is that band rounded outwards) and mark a record whose
@@ -74,7 +74,7 @@ int launch_stft_fast_rgba(const StftParams& p, void* hip_stream);
 // build_fast_table_512); colour indices and per-frame peaks.  Returns 1 if it does not serve this launch.
 int launch_stft_fast512(const StftParams& p, void* hip_stream);
 bool fast2048_rgba_available(const StftParams& p);
-bool fast512_rgba_available(const StftParams& p);  // the kernel can write the RGBA image itself (given tile_scratch)
+bool fast512_rgba_available(const StftParams& p);  // the kernel can write the RGBA image itself
 void build_fast_table_512(std::vector<float>& t);
 // kernels_fast2048.hip: the same for 2048-point frames (one complex transform per wavefront), exact roots only.
 int launch_stft_fast2048(const StftParams& p, void* hip_stream);
@@ -107,7 +107,7 @@ int launch_canvas_draw(const uint8_t* frames, uint64_t width, uint32_t bins, int
                        uint32_t height, uint32_t background, const uint32_t* lut, uint8_t* canvas, void* hip_stream);
 // True when launch_stft_fast has a kernel for this size / layout with uint8 output.
 bool fast_u8_available(const StftParams& p);
-// True when launch_stft_fast can write the RGBA image itself (given tile_scratch).
+// True when launch_stft_fast can write the RGBA image itself.
 bool fast_rgba_available(const StftParams& p);
 bool fast_features_available(const StftParams& p);
 uint64_t fast_rgba_scratch_bytes();
