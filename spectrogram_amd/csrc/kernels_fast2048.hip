@@ -161,8 +161,7 @@ __device__ __forceinline__ uint32_t put_index(float msq, const FastScale& fs, ui
   if constexpr (PLUGIN) {
     return fast_plugin_byte<BYTE>(msq, fs, acc);
   } else {
-    const float t = __builtin_floorf(__builtin_fmaf(__log2f(msq), fs.a, fs.b));
-    return __builtin_amdgcn_cvt_pk_u8_f32(t, BYTE, acc);  // saturates to [0,255]; NaN -> 0
+    return fast_worker_byte<BYTE>(msq, fs, acc);
   }
 }
 

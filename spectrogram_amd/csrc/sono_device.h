@@ -177,11 +177,19 @@ __device__ __forceinline__ uint32_t fast_index(float mag_sq, const FastScale& s)
   return __builtin_amdgcn_cvt_pk_u8_f32(t, 0, 0u);
 }
 
-// The plugin quantiser of fast_index, packed into byte BYTE of `acc`.
+// The quantisers of fast_index packed into byte BYTE of `acc`, as the transform kernels use them.  The saturating byte
+// conversion rounds to nearest (ties to even), so floor(t) is taken as round(t - 0.5): the same for every t that is not
+// an integer, and at an integer t float32 cannot tell which side of the step the reference is on anyway (the feature
+// pass marks such records and has them recomputed in the exact arithmetic).  One instruction less per bin.
 template <int BYTE>
 __device__ __forceinline__ uint32_t fast_plugin_byte(float mag_sq, const FastScale& s, uint32_t acc) {
-  const float t = __builtin_floorf(fmaxf(__builtin_fmaf(__log2f(mag_sq), s.a, s.b), s.t_floor));
+  const float t = fmaxf(__builtin_fmaf(__log2f(mag_sq), s.a, s.b - 0.5f), s.t_floor - 0.5f);
   return __builtin_amdgcn_cvt_pk_u8_f32(t, BYTE, acc);
+}
+template <int BYTE>
+__device__ __forceinline__ uint32_t fast_worker_byte(float mag_sq, const FastScale& s, uint32_t acc) {
+  const float t = __builtin_fmaf(__log2f(mag_sq), s.a, s.b - 0.5f);
+  return __builtin_amdgcn_cvt_pk_u8_f32(t, BYTE, acc);  // saturates to [0,255]; NaN -> 0
 }
 
 __device__ __forceinline__ float fast_db(float mag_sq, const FastScale& s) {
