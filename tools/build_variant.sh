@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: scratch_variant.sh NAME FILE.hip "-DFLAGS"   -> scratch/NAME/libsonospec.so (other objects from csrc/build)
+# usage: tools/build_variant.sh NAME FILE.hip "-DFLAGS"   -> scratch/NAME/libsonospec.so (other objects from csrc/build)
 set -e
 cd /root/repo/spectrogram_amd/csrc
 name=$1; file=$2; flags=$3
