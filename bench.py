@@ -216,6 +216,8 @@ def main():
         fkw = dict(fft_n=FFT_N, hop=HOP, window_id=F.WIN_WORKER_HANN, scale_mode=F.SCALE_WORKER_LOG5,
                    frame_rule=F.FRAMES_WORKER_COMPAT, twiddle_mode=F.TW_ACCURATE, arith=F.ARITH_FAST_F32, in_kind=F.IN_I16,
                    out_kind=F.OUT_RGBA8 if args.out == "rgba" else F.OUT_U8_INDEX, device=local_rank)
+        # (more than one rank: each binds to the CPUs next to its GPU before its page-locked buffers are allocated)
+        numa = sharding.bind_to_gpu_numa(local_rank) if world > 1 and not args.rehearse else None
         with sharding.FilePipeline(FL, slots=3, copy=False, **fkw) as pipe:
             for _ in pipe.run([(i, bufs[i % 4]) for i in mine[:6]]):
                 pass
@@ -228,10 +230,10 @@ def main():
             tf = torch.tensor([wall_f], dtype=torch.float64, device="cpu" if args.rehearse else dev)
             dist.all_reduce(tf, op=dist.ReduceOp.MAX)
             wall_f = float(tf.item())
-        gathered = sharding.gather_results((rank, len(mine), my_s, sums))
+        gathered = sharding.gather_results((rank, len(mine), my_s, sums, numa))
         if rank == 0:
             allsums = {}
-            for _, _, _, sm in gathered:
+            for _, _, _, sm, _ in gathered:
                 allsums.update(sm)
             ref4 = [allsums[i] for i in range(min(4, n_files))]
             files_res = {
@@ -240,8 +242,9 @@ def main():
                                 n_files, FL, "RGBA8" if args.out == "rgba" else "uint8 indices", world),
                 "files": n_files, "seconds": round(wall_f, 4), "files_per_s": round(n_files / wall_f, 1),
                 "msamples_per_s": round(n_files * FL / wall_f / 1e6, 1),
-                "per_rank": [{"rank": r, "files": nf, "seconds": round(s, 4), "msamples_per_s": round(nf * FL / s / 1e6, 1) if s > 0 else None}
-                             for r, nf, s, _ in gathered],
+                "per_rank": [{"rank": r, "files": nf, "seconds": round(s, 4), "msamples_per_s": round(nf * FL / s / 1e6, 1) if s > 0 else None,
+                              "numa_node": nn}
+                             for r, nf, s, _, nn in gathered],
                 "outputs_consistent": len(allsums) == n_files and all(allsums[i] == ref4[i % 4] for i in range(n_files)),
             }
 

@@ -156,6 +156,11 @@ typedef struct sono_geometry {
 int sono_abi_version(void);
 /* Number of GPUs the process can use; 0 when there is none (never an error). */
 int sono_device_count(void);
+/* NUMA node of the host memory closest to GPU `device` (its PCI function's numa_node in sysfs), or -1 when the
+ * platform does not say.  No counterpart in the reference (a browser page has no placement to make): hosts of the
+ * per-file batch bind a rank's threads to that node before they allocate page-locked buffers, so that the copies
+ * of the batch replacing modules/fileLoader.js:110-157 do not cross sockets. */
+int sono_device_numa_node(int device);
 
 /* ---- host-side rules (no GPU needed) ---------------------------------------------------- */
 

@@ -96,6 +96,7 @@ SYMBOLS = {
                                   C.c_void_p]),
     "sono_abi_version": (C.c_int, []),
     "sono_device_count": (C.c_int, []),
+    "sono_device_numa_node": (C.c_int, [C.c_int]),
     "sono_worker_hop": (C.c_uint32, [C.c_uint32, C.c_double]),
     "sono_plugin_noverlap": (C.c_uint32, [C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint32]),
     "sono_overlap_from_percent": (C.c_uint32, [C.c_uint32, C.c_double]),

@@ -1,6 +1,7 @@
 // C ABI of libsonospec.so: context management, host staging and kernel dispatch.
 #include <hip/hip_runtime.h>
 
+#include <cctype>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -156,6 +157,23 @@ int sono_device_count(void) {
     return 0;
   }
   return n;
+}
+
+int sono_device_numa_node(int device) {
+  char bdf[32] = {0};
+  if (hipDeviceGetPCIBusId(bdf, (int)sizeof bdf, device) != hipSuccess) {
+    (void)hipGetLastError();
+    return -1;
+  }
+  for (char* q = bdf; *q; ++q) *q = (char)tolower((unsigned char)*q);  // sysfs spells the address in lower case
+  char path[96];
+  snprintf(path, sizeof path, "/sys/bus/pci/devices/%s/numa_node", bdf);
+  FILE* f = fopen(path, "r");
+  if (!f) return -1;
+  int node = -1;
+  if (fscanf(f, "%d", &node) != 1) node = -1;
+  fclose(f);
+  return node < 0 ? -1 : node;
 }
 
 const char* sono_create_error(void) { return g_create_error.c_str(); }

@@ -88,6 +88,40 @@ def merge_calls(call_lists, min_frames=1):
     return out
 
 
+def parse_cpulist(text):
+    """A sysfs CPU list ("0-15,64-79") as a set of CPU numbers."""
+    cpus = set()
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        lo, _, hi = part.partition("-")
+        cpus.update(range(int(lo), int(hi or lo) + 1))
+    return cpus
+
+
+def bind_to_gpu_numa(device, sysfs="/sys/devices/system/node", node=None):
+    """Restricts the calling process to the CPUs of the NUMA node GPU `device` hangs off, so that the page-locked
+    buffers a `FilePipeline` allocates next (first touch) and the threads that fill them sit on the GPU's side of
+    the machine: with eight ranks each moving tens of GB/s host <-> device, copies that cross sockets are what
+    limits the per-file batch.  Best effort: returns the node, or None when the platform does not say, the node
+    has no CPU this process may use, or the affinity call is refused (the process then stays where it was)."""
+    import os
+    if node is None:
+        node = F.lib().sono_device_numa_node(int(device))
+    if node is None or node < 0:
+        return None
+    try:
+        with open(os.path.join(sysfs, "node%d" % node, "cpulist")) as fh:
+            cpus = parse_cpulist(fh.read())
+        allowed = cpus & os.sched_getaffinity(0)
+        if not allowed:
+            return None
+        os.sched_setaffinity(0, allowed)
+    except (OSError, ValueError, AttributeError):
+        return None
+    return node
+
+
 def run_file_shard(sizes, rank, world_size, load, pipeline, digest):
     """The per-file batch on one rank (the reference loads one file after the other, modules/fileLoader.js:110-157):
     this rank's share of the files (`assign_files` over `sizes`) goes through `pipeline` -- a FilePipeline, or anything

@@ -320,3 +320,20 @@ def test_feature_fixup_when_most_frames_are_doubtful():
         refp = oracle.frame_peaks_f32(mags[:8])
         assert set(refp) <= {k, k + 1}
         assert np.array_equal(ft["peak_bin"], refp) and np.array_equal(ft["peak_idx"], idx[np.arange(8), refp])
+
+
+def test_device_numa_node_and_binding():
+    """The per-file batch places a rank beside its GPU: the library names the GPU's NUMA node (or -1 when the
+    platform does not say) and the binding moves the process only onto CPUs it was allowed to use."""
+    import os
+    lib = F.lib()
+    node = lib.sono_device_numa_node(0)
+    assert isinstance(node, int) and node >= -1
+    assert lib.sono_device_numa_node(10 ** 6) == -1          # no such device: unknown, not an error
+    before = os.sched_getaffinity(0)
+    try:
+        got = sharding.bind_to_gpu_numa(0)
+        assert got is None or got == node
+        assert os.sched_getaffinity(0) <= before and os.sched_getaffinity(0)
+    finally:
+        os.sched_setaffinity(0, before)

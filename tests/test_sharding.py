@@ -209,3 +209,25 @@ def test_world_size_2_file_batch_orchestration():
     assert sorted(merged) == list(range(len(files)))
     for i, x in enumerate(files):
         assert merged[i] == zlib.crc32(oracle.worker_render(x, 1024, 75.0, None).tobytes())
+
+
+def test_bind_to_gpu_numa_uses_the_nodes_cpus(tmp_path):
+    """The rank of a per-file batch moves to the CPUs beside its GPU before it allocates page-locked buffers."""
+    assert sharding.parse_cpulist("0-3,8,10-11\n") == {0, 1, 2, 3, 8, 10, 11}
+    assert sharding.parse_cpulist("") == set()
+    before = os.sched_getaffinity(0)
+    try:
+        some = sorted(before)[: max(1, len(before) // 2)]
+        (tmp_path / "node3").mkdir()
+        (tmp_path / "node3" / "cpulist").write_text(",".join(str(c) for c in some) + "\n")
+        assert sharding.bind_to_gpu_numa(0, sysfs=str(tmp_path), node=3) == 3
+        assert os.sched_getaffinity(0) == set(some)
+        # a node whose CPUs this process may not use, a node without a list, no node: nothing changes
+        (tmp_path / "node4").mkdir()
+        (tmp_path / "node4" / "cpulist").write_text("100000-100003\n")
+        assert sharding.bind_to_gpu_numa(0, sysfs=str(tmp_path), node=4) is None
+        assert sharding.bind_to_gpu_numa(0, sysfs=str(tmp_path), node=5) is None
+        assert sharding.bind_to_gpu_numa(0, sysfs=str(tmp_path), node=-1) is None
+        assert os.sched_getaffinity(0) == set(some)
+    finally:
+        os.sched_setaffinity(0, before)

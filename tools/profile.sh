@@ -13,7 +13,7 @@ W=/tmp/prof_$TAG
 mkdir -p "$OUT" "$W"
 export TMPDIR=/tmp
 echo "[profile] kernel trace of bench.py"
-timeout -s KILL 280 rocprofv3 --kernel-trace --stats --output-format csv -d "$W/trace" -o trace -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --seconds $SEC > "$OUT/trace_bench.log" 2>&1 || { echo "trace failed"; tail -5 "$OUT/trace_bench.log"; exit 1; }
+timeout -s KILL 280 rocprofv3 --kernel-trace --stats --output-format csv -d "$W/trace" -o trace -- python3 bench.py --steps 50 --warmup 5 --no-cpu-baseline --seconds $SEC > "$OUT/trace_bench.log" 2>&1 || { echo "trace failed"; tail -5 "$OUT/trace_bench.log"; exit 1; }
 find "$W/trace" -name "*kernel_stats.csv" -exec cp {} "$OUT/bench_kernel_stats.csv" \;
 grep '^{"metric"' "$OUT/trace_bench.log" | tail -1 > "$OUT/bench_under_rocprof.json"
 pass() {
