@@ -182,6 +182,14 @@ static napi_value js_device_count(napi_env env, napi_callback_info info) {
   return make_num(env, sono_device_count());
 }
 
+/* deviceNumaNode(device) -> NUMA node of the host memory next to the GPU, -1 when unknown */
+static napi_value js_device_numa_node(napi_env env, napi_callback_info info) {
+  ARGS(env, info, 1);
+  int32_t dev = 0;
+  if (napi_get_value_int32(env, argv[0], &dev) != napi_ok) return throw_msg(env, "device must be a number");
+  return make_num(env, sono_device_numa_node(dev));
+}
+
 static napi_value js_set_colormap(napi_env env, napi_callback_info info) {
   ARGS(env, info, 2);
   handle_t* h = get_handle(env, argv[0]);
@@ -1008,6 +1016,7 @@ static napi_value js_kernel_route(napi_env env, napi_callback_info info) {
 
 static napi_value init(napi_env env, napi_value exports) {
   EXPORT("deviceCount", js_device_count);
+  EXPORT("deviceNumaNode", js_device_numa_node);
   EXPORT("create", js_create);
   EXPORT("destroy", js_destroy);
   EXPORT("setColormap", js_set_colormap);
