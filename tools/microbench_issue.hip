@@ -49,9 +49,17 @@ __global__ __launch_bounds__(1024) void phases(float* sink, int iters, int stagg
   for (int i = 0; i < 32; ++i) v[i] = (float)(threadIdx.x + i);
   float b = 1.0000001f, c = 1e-9f;
   asm volatile("" : "+v"(b), "+v"(c));
-  // stagger: the wavefronts that share a SIMD (wave, wave + 4, ...) start `stagger` x 64 cycles apart
-  for (int d = 0; d < (wave >> 2); ++d)
-    for (int e = 0; e < stagger; ++e) __builtin_amdgcn_s_sleep(1);
+  // stagger >= 0: the wavefronts that share a SIMD (wave, wave + 4, ...) start `stagger` x 64 cycles apart
+  if (stagger >= 0) {
+    for (int d = 0; d < (wave >> 2); ++d)
+      for (int e = 0; e < stagger; ++e) __builtin_amdgcn_s_sleep(1);
+  } else if (stagger == -1) {  // two of the four wavefronts of a SIMD at a higher issue priority
+    if ((wave >> 2) & 1) __builtin_amdgcn_s_setprio(3);
+  } else if (stagger == -2) {  // four priority levels
+    if ((wave >> 2) == 1) __builtin_amdgcn_s_setprio(1);
+    if ((wave >> 2) == 2) __builtin_amdgcn_s_setprio(2);
+    if ((wave >> 2) == 3) __builtin_amdgcn_s_setprio(3);
+  }
   for (int it = 0; it < iters; ++it) {
     if (MODE != 2) {
 #pragma unroll
@@ -148,7 +156,7 @@ int main() {
              ms * 1e6 / pit);                                                                          \
     }                                                                                                  \
   } while (0)
-  for (int stag = 0; stag <= 40; stag += 20) {
+  for (int stag = -2; stag <= 20; stag += (stag < 0 ? 1 : 20)) {
     PH(640, 0);
     PH(640, 1);
     PH(640, 2);
