@@ -227,6 +227,10 @@ __global__ __launch_bounds__(kMaxWaves * 64, 4) void stft1024_u8_kernel(StftPara
     float best_a = -1.0f, best_b = -1.0f;  // FEAT: this lane's largest |X|^2 so far and its bin
     float next_a = -1.0f, next_b = -1.0f;  // FEAT: ... and the runner-up (what decides whether float32 can tell)
     int kbest_a = (int)p.bin_lo, kbest_b = (int)p.bin_lo;
+    // FEAT, band narrower than the spectrum: the largest |X|^2 of any bin of either frame (what the transform's
+    // rounding noise and the pair's cross-talk scale with; see feature_uncertain)
+    const bool banded = p.bin_lo != 0 || p.bin_hi != kNPoints / 2;  // wave-uniform
+    float seen_a = 0.0f, seen_b = 0.0f;
     int lq = l;
     // (FEAT: an opaque copy keeps the loop-invariant bin numbers and band tests out of registers the transform needs;
     // hoisted, they were spilled and every reload waited on the memory counter)
@@ -276,6 +280,10 @@ __global__ __launch_bounds__(kMaxWaves * 64, 4) void stft1024_u8_kernel(StftPara
         SONO_BIN(3, z23.z, z23.w, q23.z, q23.w)
 #undef SONO_BIN
         if constexpr (FEAT) {
+          if (banded) {
+            seen_a = fmaxf(fmaxf(fmaxf(seen_a, fa[0]), fa[1]), fmaxf(fa[2], fa[3]));
+            seen_b = fmaxf(fmaxf(fmaxf(seen_b, fb[0]), fb[1]), fmaxf(fb[2], fb[3]));
+          }
           if (in_band) {  // (one branch per bin quad; selects inside)
 #pragma unroll
             for (int B = 0; B < 4; ++B) {  // a lane visits its bins in ascending order
@@ -305,6 +313,11 @@ __global__ __launch_bounds__(kMaxWaves * 64, 4) void stft1024_u8_kernel(StftPara
       // reduce over the 32 lanes of the half-wavefront: larger |X|^2 wins, equal values go to the lower bin
       reduce_peak<32>(best_a, kbest_a, next_a);
       reduce_peak<32>(best_b, kbest_b, next_b);
+      if (banded) {
+        seen_a = reduce_max<32>(seen_a);
+        seen_b = reduce_max<32>(seen_b);
+      }
+      const float top_a = fmaxf(best_a, seen_a), top_b = fmaxf(best_b, seen_b);  // the frames' largest |X|^2 anywhere
       if (l == 0) {
         sono_frame_feature* ft = reinterpret_cast<sono_frame_feature*>(p.out) + (p.col0 + f0);
         // reserved[0] = 1: float32 cannot tell (two top bins too close, or the peak too close to a step of the
@@ -314,7 +327,7 @@ __global__ __launch_bounds__(kMaxWaves * 64, 4) void stft1024_u8_kernel(StftPara
           sono_frame_feature r{};
           r.peak_bin = kbest_a;
           r.peak_idx = (uint8_t)put_index<PLUGIN, 0>(best_a, fs, 0);
-          r.reserved[0] = (feature_uncertain(best_a, next_a, best_b, ta, fs) || peak_outside(kbest_a, p.feat_lo, p.feat_hi)) ? 1 : 0;
+          r.reserved[0] = (feature_uncertain(best_a, next_a, top_b, top_a, ta, fs) || peak_outside(kbest_a, p.feat_lo, p.feat_hi)) ? 1 : 0;
           ft[0] = r;
           if (r.reserved[0] && p.feat_queue) {  // (a few frames per thousand)
             const uint32_t at = atomicAdd(p.feat_queue, 1u);
@@ -325,7 +338,7 @@ __global__ __launch_bounds__(kMaxWaves * 64, 4) void stft1024_u8_kernel(StftPara
           sono_frame_feature r{};
           r.peak_bin = kbest_b;
           r.peak_idx = (uint8_t)put_index<PLUGIN, 0>(best_b, fs, 0);
-          r.reserved[0] = (feature_uncertain(best_b, next_b, best_a, tb, fs) || peak_outside(kbest_b, p.feat_lo, p.feat_hi)) ? 1 : 0;
+          r.reserved[0] = (feature_uncertain(best_b, next_b, top_a, top_b, tb, fs) || peak_outside(kbest_b, p.feat_lo, p.feat_hi)) ? 1 : 0;
           ft[1] = r;
           if (r.reserved[0] && p.feat_queue) {
             const uint32_t at = atomicAdd(p.feat_queue, 1u);

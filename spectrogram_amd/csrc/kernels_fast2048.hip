@@ -394,6 +394,10 @@ __global__ __launch_bounds__(kWaves * 64) void stft2048_kernel(StftParams p, Fas
     int kbest_a = (int)p.bin_lo, kbest_b = (int)p.bin_lo;
     const uint64_t row_a = (p.col0 + fb) * p.out_bins, row_b = row_a + p.out_bins;
     const bool st_a = fb >= f0, st_b = true;  // fb + 1 < nframes always; frame fb belongs to this wavefront unless shifted
+    // FEAT, band narrower than the spectrum: the largest |X|^2 of any bin of either frame (what the transform's
+    // rounding noise and the pair's cross-talk scale with; see feature_uncertain)
+    const bool banded = p.bin_lo != 0 || p.bin_hi != 1024;  // wave-uniform
+    float seen_a = 0.0f, seen_b = 0.0f;
 #pragma unroll
     for (int P = 0; P < 2; ++P) {
       if constexpr (TABLE) epilogue_cells_table(P, re, im, cell, le); else epilogue_cells(P, re, im, cell, kappa);
@@ -429,6 +433,10 @@ __global__ __launch_bounds__(kWaves * 64) void stft2048_kernel(StftParams p, Fas
         SONO_BIN(3, z23.z, z23.w, q23.z, q23.w)
 #undef SONO_BIN
         if constexpr (FEAT) {
+          if (banded) {
+            seen_a = fmaxf(fmaxf(fmaxf(seen_a, pa[0]), pa[1]), fmaxf(pa[2], pa[3]));
+            seen_b = fmaxf(fmaxf(fmaxf(seen_b, pb[0]), pb[1]), fmaxf(pb[2], pb[3]));
+          }
           if (in_band) {  // (one branch per bin quad; selects inside)
 #pragma unroll
             for (int B = 0; B < 4; ++B) {
@@ -452,6 +460,11 @@ __global__ __launch_bounds__(kWaves * 64) void stft2048_kernel(StftParams p, Fas
       // larger |X|^2 wins, equal values go to the lower bin
       reduce_peak<64>(best_a, kbest_a, next_a);
       reduce_peak<64>(best_b, kbest_b, next_b);
+      if (banded) {
+        seen_a = reduce_max<64>(seen_a);
+        seen_b = reduce_max<64>(seen_b);
+      }
+      const float top_a = fmaxf(best_a, seen_a), top_b = fmaxf(best_b, seen_b);  // the frames' largest |X|^2 anywhere
       if (lane == 0) {
         // reserved[0] = 1: float32 cannot tell; the exact-arithmetic pass that follows recomputes the record
         sono_frame_feature* ft = reinterpret_cast<sono_frame_feature*>(p.out) + (p.col0 + fb);
@@ -460,13 +473,13 @@ __global__ __launch_bounds__(kWaves * 64) void stft2048_kernel(StftParams p, Fas
           sono_frame_feature r{};
           r.peak_bin = kbest_a;
           r.peak_idx = (uint8_t)put_index<PLUGIN, 0>(best_a, fs, 0);
-          r.reserved[0] = (feature_uncertain(best_a, next_a, best_b, ta, fs) || peak_outside(kbest_a, p.feat_lo, p.feat_hi)) ? 1 : 0;
+          r.reserved[0] = (feature_uncertain(best_a, next_a, top_b, top_a, ta, fs) || peak_outside(kbest_a, p.feat_lo, p.feat_hi)) ? 1 : 0;
           ft[0] = r;
         }
         sono_frame_feature r{};
         r.peak_bin = kbest_b;
         r.peak_idx = (uint8_t)put_index<PLUGIN, 0>(best_b, fs, 0);
-        r.reserved[0] = (feature_uncertain(best_b, next_b, best_a, tb, fs) || peak_outside(kbest_b, p.feat_lo, p.feat_hi)) ? 1 : 0;
+        r.reserved[0] = (feature_uncertain(best_b, next_b, top_a, top_b, tb, fs) || peak_outside(kbest_b, p.feat_lo, p.feat_hi)) ? 1 : 0;
         ft[1] = r;
       }
     }

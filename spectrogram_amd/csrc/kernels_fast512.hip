@@ -314,6 +314,10 @@ __global__ __launch_bounds__(kWaves * 64) void stft512_kernel(StftParams p, Fast
     float best[4] = {-1.0f, -1.0f, -1.0f, -1.0f};  // FEAT: largest |X|^2 so far of frame 2q + {0, 1}, q = transform read
     int kbest[4] = {(int)p.bin_lo, (int)p.bin_lo, (int)p.bin_lo, (int)p.bin_lo};
     float next[4] = {-1.0f, -1.0f, -1.0f, -1.0f};  // FEAT: the runner-up (decides whether float32 can tell)
+    // FEAT, band narrower than the spectrum: the largest |X|^2 of any bin of each frame (what the transform's rounding
+    // noise and the pair's cross-talk scale with; see feature_uncertain)
+    const bool banded = p.bin_lo != 0 || p.bin_hi != 256;  // wave-uniform
+    float seen[4] = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
     for (int P = 0; P < 2; ++P) {
       epilogue_cells(P, re, im, cell, le);
@@ -350,6 +354,10 @@ __global__ __launch_bounds__(kWaves * 64) void stft512_kernel(StftParams p, Fast
         SONO_BIN(3, z23.z, z23.w, q23.z, q23.w)
 #undef SONO_BIN
         if constexpr (FEAT) {
+          if (banded) {
+            seen[2 * q] = fmaxf(fmaxf(fmaxf(seen[2 * q], pa[0]), pa[1]), fmaxf(pa[2], pa[3]));
+            seen[2 * q + 1] = fmaxf(fmaxf(fmaxf(seen[2 * q + 1], pb[0]), pb[1]), fmaxf(pb[2], pb[3]));
+          }
           if (in_band) {  // (one branch per bin quad; selects inside)
 #pragma unroll
             for (int B = 0; B < 4; ++B) {
@@ -378,6 +386,8 @@ __global__ __launch_bounds__(kWaves * 64) void stft512_kernel(StftParams p, Fast
         reduce_peak<32>(best[i], kbest[i], next[i]);
       }
 #pragma unroll
+      for (int i = 0; i < 4; ++i) seen[i] = fmaxf(best[i], banded ? reduce_max<32>(seen[i]) : 0.0f);  // the frame's largest |X|^2 anywhere
+#pragma unroll
       for (int i = 0; i < 4; ++i) {
         const uint64_t fr = fb + i;
         if (l == 0 && fr >= f0 && fr < p.nframes) {
@@ -385,7 +395,8 @@ __global__ __launch_bounds__(kWaves * 64) void stft512_kernel(StftParams p, Fast
           sono_frame_feature r{};
           r.peak_bin = kbest[i];
           r.peak_idx = (uint8_t)put_index<PLUGIN, 0>(best[i], fs, 0);
-          r.reserved[0] = (feature_uncertain(best[i], next[i], best[i ^ 1], __builtin_fmaf(__log2f(best[i]), fs.a, fs.b), fs) ||
+          r.reserved[0] = (feature_uncertain(best[i], next[i], seen[i ^ 1], seen[i],
+                                             __builtin_fmaf(__log2f(best[i]), fs.a, fs.b), fs) ||
                            peak_outside(kbest[i], p.feat_lo, p.feat_hi)) ? 1 : 0;
           reinterpret_cast<sono_frame_feature*>(p.out)[p.col0 + fr] = r;
         }

@@ -105,6 +105,7 @@ __global__ __launch_bounds__((1 << LOG2N) / 16 * G, 4) void stft_mw_kernel(StftP
   __shared__ float s_best[FEAT ? G * kWavesPerGroup * 2 : 1];   // FEAT, transforms wider than a wavefront:
   __shared__ int s_bestk[FEAT ? G * kWavesPerGroup * 2 : 1];    // per-wavefront peaks of the two frames
   __shared__ float s_next[FEAT ? G * kWavesPerGroup * 2 : 1];   // ... and their runners-up
+  __shared__ float s_zmax[FEAT ? G * kWavesPerGroup : 1];       // ... and the largest component of the pair's transform
   static_assert(CB >= 1 && CB <= 4, "512 to 4096 points");
   constexpr int kPlane = N + N / 32;
   __shared__ float s_re_all[G][kPlane], s_im_all[G][kPlane];
@@ -189,6 +190,7 @@ __global__ __launch_bounds__((1 << LOG2N) / 16 * G, 4) void stft_mw_kernel(StftP
       s_im[cellB + 16 * b + (b >> 1)] = im[b];
     }
     group_sync<TN>();
+    float zmax = 0.0f;
 #pragma unroll
     for (int s = 0; s < SETS; ++s) {
       const int w = t + TN * s;
@@ -205,6 +207,8 @@ __global__ __launch_bounds__((1 << LOG2N) / 16 * G, 4) void stft_mw_kernel(StftP
       for (int c = 0; c < NC; ++c) {  // X[c*256 + w], again in the thread's own cells
         s_re[cellC + 264 * c] = re[s * NC + c];
         s_im[cellC + 264 * c] = im[s * NC + c];
+        // FEAT: the largest component of the transform (what its rounding noise scales with; see feature_uncertain)
+        if constexpr (FEAT) zmax = fmaxf(zmax, fmaxf(fabsf(re[s * NC + c]), fabsf(im[s * NC + c])));
       }
     }
     group_sync<TN>();
@@ -267,10 +271,12 @@ __global__ __launch_bounds__((1 << LOG2N) / 16 * G, 4) void stft_mw_kernel(StftP
       for (int msk = 1; msk < (TN < 64 ? TN : 64); msk <<= 1) {
         take(best_a, kbest_a, next_a, __shfl_xor(best_a, msk, 64), __shfl_xor(kbest_a, msk, 64), __shfl_xor(next_a, msk, 64));
         take(best_b, kbest_b, next_b, __shfl_xor(best_b, msk, 64), __shfl_xor(kbest_b, msk, 64), __shfl_xor(next_b, msk, 64));
+        zmax = fmaxf(zmax, __shfl_xor(zmax, msk, 64));
       }
       if constexpr (kWavesPerGroup > 1) {
         const int wv = t >> 6;
         if ((t & 63) == 0) {
+          s_zmax[grp * kWavesPerGroup + wv] = zmax;
           s_best[(grp * kWavesPerGroup + wv) * 2] = best_a;     s_bestk[(grp * kWavesPerGroup + wv) * 2] = kbest_a;
           s_best[(grp * kWavesPerGroup + wv) * 2 + 1] = best_b; s_bestk[(grp * kWavesPerGroup + wv) * 2 + 1] = kbest_b;
           s_next[(grp * kWavesPerGroup + wv) * 2] = next_a;     s_next[(grp * kWavesPerGroup + wv) * 2 + 1] = next_b;
@@ -283,6 +289,7 @@ __global__ __launch_bounds__((1 << LOG2N) / 16 * G, 4) void stft_mw_kernel(StftP
                  s_next[(grp * kWavesPerGroup + v) * 2]);
             take(best_b, kbest_b, next_b, s_best[(grp * kWavesPerGroup + v) * 2 + 1], s_bestk[(grp * kWavesPerGroup + v) * 2 + 1],
                  s_next[(grp * kWavesPerGroup + v) * 2 + 1]);
+            zmax = fmaxf(zmax, s_zmax[grp * kWavesPerGroup + v]);
           }
         }
       }
@@ -290,18 +297,20 @@ __global__ __launch_bounds__((1 << LOG2N) / 16 * G, 4) void stft_mw_kernel(StftP
         // reserved[0] = 1: float32 cannot tell; the exact-arithmetic pass that follows recomputes the record
         sono_frame_feature* ft = reinterpret_cast<sono_frame_feature*>(p.out) + (p.col0 + f0);
         const float ta = __builtin_fmaf(__log2f(best_a), fs.a, fs.b), tb = __builtin_fmaf(__log2f(best_b), fs.a, fs.b);
+        // either frame's largest |2X|^2 anywhere is at most |2Z|^2 <= 4 (re^2 + im^2) <= 8 zmax^2
+        const float top = fmaxf(fmaxf(best_a, best_b), 8.0f * zmax * zmax);
         if (st_a) {
           sono_frame_feature r{};
           r.peak_bin = kbest_a;
           r.peak_idx = (uint8_t)put_index<PLUGIN, 0>(best_a, fs, 0);
-          r.reserved[0] = (feature_uncertain(best_a, next_a, best_b, ta, fs) || peak_outside(kbest_a, p.feat_lo, p.feat_hi)) ? 1 : 0;
+          r.reserved[0] = (feature_uncertain(best_a, next_a, top, top, ta, fs) || peak_outside(kbest_a, p.feat_lo, p.feat_hi)) ? 1 : 0;
           ft[0] = r;
         }
         if (active) {
           sono_frame_feature r{};
           r.peak_bin = kbest_b;
           r.peak_idx = (uint8_t)put_index<PLUGIN, 0>(best_b, fs, 0);
-          r.reserved[0] = (feature_uncertain(best_b, next_b, best_a, tb, fs) || peak_outside(kbest_b, p.feat_lo, p.feat_hi)) ? 1 : 0;
+          r.reserved[0] = (feature_uncertain(best_b, next_b, top, top, tb, fs) || peak_outside(kbest_b, p.feat_lo, p.feat_hi)) ? 1 : 0;
           ft[1] = r;
         }
       }

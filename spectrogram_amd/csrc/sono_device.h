@@ -123,21 +123,49 @@ struct FastScale {
 };
 
 // Feature pass of the float32 kernels: a frame's record is exact unless the float32 arithmetic cannot tell.  With
-// P1 >= P2 the two largest |X|^2 of the band, Pp the largest of the frame transformed with it, and t the quantiser
-// argument of P1: the float32 powers are within kTieRel (measured error < 1e-6; 40x margin) plus the pair's
-// cross-talk of the reference's, so the argmax is safe if P1 - P2 exceeds that, and the colour index is safe if t
-// is further from an integer than the same error scaled by d t / d ln P, plus the error of v_log_f32.  Anything
-// else is marked and recomputed in the exact arithmetic (launch_features_fixup).
+// P1 >= P2 the two largest |X|^2 of the band, Tp and To the largest |X|^2 ANYWHERE in the spectrum of the frame
+// transformed with it and of the frame itself, and t the quantiser argument of P1: the float32 powers are within
+// kTieRel (measured error < 1e-6; 40x margin) of the reference's, plus the pair's cross-talk under an asymmetric
+// twiddle table (a share of the partner's largest magnitude: a perturbed butterfly spreads over all bins), plus the
+// transform's rounding noise, which scales with the LARGEST value in the transform and not with the band's own -- a
+// silent frame paired with a loud one, or a band that leaves out the loud bins, holds nothing but that (kLeak times
+// the largest magnitude).  The argmax is safe if P1 - P2 exceeds all of that, and the colour index is safe if t is
+// further from an integer than the same error scaled by d t / d ln P, plus the error of v_log_f32.  Anything else is
+// marked and recomputed in the exact arithmetic (launch_features_fixup).  A band that is exactly zero in a pair that
+// is not is marked as well: the reference's values may be tiny rather than zero.
+// (When the band is the whole spectrum Tp and To are the two frames' band peaks; otherwise the kernels keep the
+// largest power of any bin they compute.)
 constexpr float kTieRel = 4e-5f;
-__device__ __forceinline__ bool feature_uncertain(float p1, float p2, float pp, float t, const FastScale& s) {
-  if (!(p1 > 0.0f)) return false;  // an all-zero band is all-zero in every arithmetic: first bin, index from |X| = 0
-  const float q = s.xtalk * __builtin_amdgcn_sqrtf(pp) * __builtin_amdgcn_rsqf(p1);   // |leak| / |X|: power error 2q + q^2
+constexpr float kLeak = 1e-6f;  // of the larger of the two largest magnitudes: measured 1.5e-7 .. 1.8e-7 at 512 .. 4096 points (tools/leak_probe.py)
+__device__ __forceinline__ bool feature_uncertain(float p1, float p2, float tp, float to, float t, const FastScale& s) {
+  const float big = fmaxf(tp, to);
+  if (!(p1 > 0.0f)) return p1 == 0.0f && big > 0.0f;  // all-zero everywhere: first bin, index from |X| = 0, in every arithmetic
+  const float q = fmaxf(s.xtalk * __builtin_amdgcn_sqrtf(tp), kLeak * __builtin_amdgcn_sqrtf(big)) *
+                  __builtin_amdgcn_rsqf(p1);                 // |error| / |X|: power error 2q + q^2
   const float rel = __builtin_fmaf(q, 2.0f + q, kTieRel);  // relative error bound of P1 (and, in units of P1, of P2)
   const bool tie = p1 - p2 <= 2.0f * rel * p1;
   const float fr = __builtin_amdgcn_fractf(t);
   const float dt = __builtin_fmaf(s.tscale, rel, 2e-4f);
   const bool edge = !(fr > dt && fr < 1.0f - dt) && t > -1.0f && t < 257.0f;
   return tie || edge;
+}
+
+// The largest value over the WIDTH (32 or 64) lanes of a transform, in every lane (vector ALU only, like reduce_peak).
+template <int WIDTH>
+__device__ __forceinline__ float reduce_max(float c) {
+  c = __builtin_fmaxf(c, dpp_f<kDppXor1>(c));
+  c = __builtin_fmaxf(c, dpp_f<kDppXor2>(c));
+  c = __builtin_fmaxf(c, dpp_f<kDppRor4>(c));
+  c = __builtin_fmaxf(c, dpp_f<kDppRor8>(c));
+  {
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(c), __float_as_uint(c), false, false);
+    c = __builtin_fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+  }
+  if constexpr (WIDTH == 64) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(c), __float_as_uint(c), false, false);
+    c = __builtin_fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+  }
+  return c;
 }
 
 __host__ __device__ inline FastScale make_fast_scale(uint32_t mode, uint32_t n, double gain, double range) {

@@ -1,0 +1,163 @@
+"""Seeded random configurations of the hot path against the CPU checker.
+
+The kernels have many routes (four transform sizes, exact-root and table-twiddle flavours, hops with and without
+shared sample loads, bands inside and across groups of four bins, float32 and int16 samples, colour indices, images
+and feature records, frame counts around the block and round sizes of the image writers).  The fixed cases of the
+other files pin the routes one by one; this file draws combinations nobody thought of.  Tolerances as everywhere:
+float32 arithmetic within 1 LSB of the checker's colour index (cyclic at the plugin's 256 -> 0 wrap, at most 2 % of the
+bins off), feature records and everything in the exact arithmetic bit-identical.
+"""
+import numpy as np
+import pytest
+
+import oracle
+from spectrogram_amd import _ffi as F
+from spectrogram_amd import engine as E
+
+pytestmark = pytest.mark.gpu
+
+# a colour table whose red channel is a permutation of 0..255, so that a pixel names its index
+_PERM = np.random.default_rng(99).permutation(256).astype(np.uint8)
+_INV = np.argsort(_PERM).astype(np.int16)
+LUT = np.stack([_PERM, (np.arange(256) * 7 % 256).astype(np.uint8), (255 - np.arange(256)).astype(np.uint8),
+                np.full(256, 255, np.uint8)], axis=1).reshape(-1)
+
+
+def cyc_diff(a, b):
+    d = (a.astype(np.int16) - b.astype(np.int16)) % 256
+    return np.minimum(d, 256 - d)
+
+
+def draw_config(rng):
+    n = int(rng.choice([512, 1024, 1024, 2048, 4096]))
+    hop = int(rng.choice([n // 4, n // 2, n // 8, n // 16, int(rng.integers(n // 16, n + 1))]))
+    path = str(rng.choice(["worker", "plugin"]))
+    if path == "worker":                                   # the worker derives its hop from a percentage
+        hop = E.worker_hop(n, 100.0 * (1 - hop / n))
+    out = str(rng.choice(["u8", "rgba", "features"]))
+    frames = int(rng.choice([int(rng.integers(3, 40)), int(rng.integers(40, 700)), int(rng.integers(700, 1600))]))
+    extra = int(rng.choice([0, int(rng.integers(0, hop))]))
+    bins = n // 2
+    if rng.random() < 0.5:
+        lo, hi = 0, bins
+    else:
+        lo = int(rng.integers(0, bins - 8))
+        hi = int(rng.integers(lo + 5, bins + 1))
+    return dict(n=n, hop=hop, path=path, out=out, L=n + hop * (frames - 1) + extra, lo=lo, hi=hi,
+                i16=bool(rng.random() < 0.3), exact=bool(rng.random() < 0.15))
+
+
+def signal(rng, L):
+    x = rng.standard_normal(L) * 10.0 ** rng.uniform(-3, -1)
+    t = np.arange(L, dtype=np.float64)
+    f0, f1 = rng.uniform(0.01, 0.45, 2)
+    x += 10.0 ** rng.uniform(-2, -0.2) * np.sin(2 * np.pi * (f0 * t + (f1 - f0) * t * t / (2 * L)))     # a sweep
+    if rng.random() < 0.5:
+        a = int(rng.integers(0, L // 2))
+        x[a:a + L // 5] = 0.0                                                                            # a stretch of silence
+    return np.clip(x, -1, 1).astype(np.float32)
+
+
+def engine_of(c, out_kind):
+    kw = dict(fft_n=c["n"], hop=c["hop"], arith=F.ARITH_EXACT_F64 if c["exact"] else F.ARITH_FAST_F32, out_kind=out_kind,
+              in_kind=F.IN_I16 if c["i16"] else F.IN_F32, bin_lo=c["lo"], bin_hi=c["hi"] if (c["lo"], c["hi"]) != (0, c["n"] // 2) else 0)
+    if c["path"] == "worker":
+        return E.Engine(window_id=F.WIN_WORKER_HANN, scale_mode=F.SCALE_WORKER_LOG5, frame_rule=F.FRAMES_WORKER_COMPAT,
+                        twiddle_mode=F.TW_ACCURATE, **kw)
+    return E.Engine(window_id=F.WINDOW_IDS["hann"], gain_db=20.0, range_db=80.0, scale_mode=F.SCALE_PLUGIN_DB,
+                    frame_rule=F.FRAMES_PLUGIN_STRICT, twiddle_mode=F.TW_PLUGIN_RECURRENCE, **kw)
+
+
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("SONO_RANDOM_CASES", "48"))))
+def test_random_configuration_against_checker(seed):
+    rng = np.random.default_rng(1000 + seed)
+    c = draw_config(rng)
+    x = signal(rng, c["L"])
+    if c["i16"]:
+        q = np.round(x * 32767).astype(np.int16)
+        x_in, x = q, (q.astype(np.float32) / np.float32(32768.0))        # the value of an int16 sample is s / 32768
+    else:
+        x_in = x
+    n, hop, lo, hi = c["n"], c["hop"], c["lo"], c["hi"]
+    # the checker: indices [frame][bin] (and, for the features, float32 magnitudes)
+    if c["path"] == "worker":
+        pct = 100.0 * (1 - hop / n)
+        assert E.worker_hop(n, pct) == hop
+        ref_img, ref_idx = oracle.worker_render(x, n, pct, LUT, want_index=True)
+        mags = None
+    else:
+        ref_idx, mags, _, _ = oracle.plugin_get_frequencies(x, n, n - hop, want_mags=True)
+        ref_img = None
+    if c["out"] == "features" and c["path"] == "worker":
+        mags, _ = oracle.worker_magnitudes(x, n, hop, ref_idx.shape[0])
+    exact = c["exact"]
+    tag = repr(c)
+    if c["out"] == "u8":
+        with engine_of(c, F.OUT_U8_INDEX) as eng:
+            got = eng.stft(x_in)
+        want = ref_idx[:, lo:hi]
+        assert got.shape == want.shape, tag
+        if exact:
+            assert np.array_equal(got, want), tag
+        else:
+            d = cyc_diff(got, want)
+            assert d.max(initial=0) <= 1 and (d != 0).mean() < 0.02, tag
+    elif c["out"] == "rgba":
+        with engine_of(c, F.OUT_RGBA8) as eng:
+            eng.set_colormap(LUT)
+            got = eng.stft(x_in)
+        if c["path"] == "worker":
+            want_img = ref_img[n // 2 - hi:n // 2 - lo]                       # the band is a crop of the image
+        else:
+            want_img = LUT.reshape(256, 4)[ref_idx[:, lo:hi].T[::-1]]
+        assert got.shape == want_img.shape, tag
+        if exact:
+            assert np.array_equal(got, want_img), tag
+        else:
+            gi, wi = _INV[got[..., 0]], _INV[want_img[..., 0]]
+            assert np.array_equal(got, LUT.reshape(256, 4)[gi]), tag           # every pixel is an entry of the table
+            d = cyc_diff(gi, wi) if c["path"] == "plugin" else np.abs(gi - wi)
+            assert d.max(initial=0) <= 1 and (d != 0).mean() < 0.02, tag
+    else:
+        with engine_of(c, F.OUT_FEATURES) as eng:
+            ft = eng.stft(x_in)
+        want_bin = oracle.frame_peaks_f32(mags, lo, hi)
+        assert np.array_equal(ft["peak_bin"], want_bin), tag
+        assert np.array_equal(ft["peak_idx"], ref_idx[np.arange(len(want_bin)), want_bin]), tag
+
+
+@pytest.mark.parametrize("n", [512, 1024, 2048, 4096])
+@pytest.mark.parametrize("path", ["worker", "plugin"])
+def test_features_of_silent_frames_beside_loud_ones(n, path):
+    """The float32 kernels transform two frames at once, so a frame of digital silence (or a band that leaves out a
+    loud tone) holds the other frame's rounding noise, about 2e-7 of its peak: such records must come from the
+    exact-arithmetic pass, not from the noise.  Blocks of two frame lengths -- a loud tone, exact zeros, very quiet
+    noise, the tone again -- at 50 % overlap, so that whole frames are silent and every pairing occurs; once over the
+    whole spectrum, once over a band beside the tone."""
+    hop = n // 2
+    assert E.worker_hop(n, 50.0) == hop
+    rng = np.random.default_rng(n)
+    blocks = 48
+    x = np.zeros(2 * n * blocks + 7, np.float32)
+    t = np.arange(2 * n, dtype=np.float64)
+    tone_bin = n // 8
+    for b in range(blocks):
+        kind = b % 4
+        if kind in (0, 3):
+            x[2 * n * b:2 * n * (b + 1)] = (0.8 * np.sin(2 * np.pi * (tone_bin + 0.3) / n * t + b)).astype(np.float32)
+        elif kind == 2:
+            x[2 * n * b:2 * n * (b + 1)] = (rng.standard_normal(2 * n) * 1e-5).astype(np.float32)
+    if path == "worker":
+        _, ref_idx = oracle.worker_render(x, n, 50.0, None, want_index=True)
+        mags, _ = oracle.worker_magnitudes(x, n, hop, ref_idx.shape[0])
+    else:
+        ref_idx, mags, _, _ = oracle.plugin_get_frequencies(x, n, n - hop, want_mags=True)
+    for lo, hi in ((0, n // 2), (tone_bin + n // 16 + 1, n // 2 - 3)):
+        c = dict(n=n, hop=hop, path=path, lo=lo, hi=hi, i16=False, exact=False)
+        with engine_of(c, F.OUT_FEATURES) as eng:
+            ft = eng.stft(x)
+            redone = eng.features_recomputed()
+        want_bin = oracle.frame_peaks_f32(mags, lo, hi)
+        assert len(ft) == len(want_bin) and np.array_equal(ft["peak_bin"], want_bin), (n, path, lo, hi)
+        assert np.array_equal(ft["peak_idx"], ref_idx[np.arange(len(want_bin)), want_bin]), (n, path, lo, hi)
+        assert redone >= blocks // 4, (n, path, lo, hi, redone)     # silent frames beside loud ones were recomputed
