@@ -79,7 +79,10 @@ typedef enum sono_twiddle_mode {
 } sono_twiddle_mode;
 
 typedef enum sono_arith {
-  SONO_ARITH_FAST_F32 = 0, /* float32 kernels; dB within 0.01 dB, indices within 1 LSB          */
+  SONO_ARITH_FAST_F32 = 0, /* float32 kernels; dB within 0.01 dB, indices within 1 LSB.  Holds while the
+                              plugin quantiser's floor -gain_db-range_db is no lower than -100 dB (the
+                              reference's defaults 20 / 80 are); a context created with a lower floor
+                              computes colour indices and images in the exact arithmetic instead      */
   SONO_ARITH_EXACT_F64 = 1 /* the reference's radix-2 dataflow in double with a float32 rounding
                               at every store, no FMA: magnitudes bit-identical to the JavaScript */
 } sono_arith;

@@ -52,6 +52,7 @@ struct sono_ctx {
   bool fb_mw_ok = false;
   bool pair_exact = false;  // StftParams::pair_exact
   double pair_asym = 0;     // StftParams::pair_asym
+  bool pair_idx_ok = true;  // StftParams::pair_idx_ok
   std::string route;        // kernels of the most recent transform call (sono_kernel_route)
   std::string err;
 };
@@ -235,6 +236,16 @@ sono_ctx* sono_create(int device, const sono_config* cfg) {
   if (!c) return nullptr;
   c->device = device;
   c->cfg = *cfg;
+  // The float32 arithmetic resolves about 100 dB below the loudest value of a transform (its own rounding, and under
+  // the plugin's recurrence factors the cross-talk between the two frames transformed together): a full-scale burst
+  // beside silence stays within 1 LSB of the reference down to a display floor of -100 dB and not below (measured at
+  // 512 .. 4096 points).  A quantiser whose floor -gain-range lies lower would show that noise where the reference
+  // shows its own, so such a context computes colour indices and images in the exact arithmetic.
+  if (c->cfg.arith == SONO_ARITH_FAST_F32 && c->cfg.scale_mode == SONO_SCALE_PLUGIN_DB &&
+      (c->cfg.out_kind == SONO_OUT_U8_INDEX || c->cfg.out_kind == SONO_OUT_RGBA8) &&
+      (double)c->cfg.gain_db + (double)c->cfg.range_db > 100.0)
+    c->cfg.arith = SONO_ARITH_EXACT_F64;
+  cfg = &c->cfg;
   c->bin_lo = cfg->bin_lo;
   c->bin_hi = cfg->bin_hi ? cfg->bin_hi : n / 2;
   c->h_window = std::move(win);
@@ -434,6 +445,18 @@ static int refresh_routes(sono_ctx* c) {
   c->fb_mw_ok = c->d_fb_bin ? compute_mw_ok(c, true) : false;
   c->pair_asym = table_asymmetry(c);
   c->pair_exact = c->pair_asym <= 5e-7;
+  {
+    // The largest |X| a frame of samples within +-1 can reach under this window is the sum of the window; its trace in
+    // the frame transformed with it is pair_asym times that.  Plugin scale: index 0 below r = 20 log10(2/N |X|) =
+    // -gain-range; worker scale: index 0 up to |X| = 1.  One decibel of margin.
+    double wsum = 0;
+    for (float w : c->h_window) wsum += std::fabs((double)w);
+    const double ghost = c->pair_asym * wsum;
+    const double floor_mag = c->cfg.scale_mode == SONO_SCALE_PLUGIN_DB
+                                 ? 0.5 * (double)c->cfg.fft_n * std::pow(10.0, -((double)c->cfg.gain_db + (double)c->cfg.range_db) / 20.0)
+                                 : 1.0;
+    c->pair_idx_ok = c->pair_exact || ghost <= floor_mag * std::pow(10.0, -1.0 / 20.0);
+  }
   const bool ragged_u8 = c->cfg.out_kind == SONO_OUT_U8_INDEX && ((c->bin_lo | c->bin_hi) & 3u) && (c->fast_mode || c->mw_ok);
   const bool fb_route = (c->fb_fast_mode || c->fb_mw_ok) && (c->cfg.out_kind == SONO_OUT_RGBA8 || c->cfg.out_kind == SONO_OUT_U8_INDEX);
   if (c->cfg.out_kind == SONO_OUT_RGBA8 || ragged_u8 || fb_route) {
@@ -569,7 +592,7 @@ static int launch_range(sono_ctx* c, const StftParams& q, const IndexScratch& au
         m.out = mags;
         m.fast_mode = c->fb_fast_mode;
         m.mw_ok = c->fb_mw_ok ? 1u : 0u;
-        m.pair_exact = 1;  // (the cross-talk of an asymmetric table is far below a step of the quantiser)
+        m.pair_exact = c->pair_idx_ok ? 1 : q.pair_exact;  // (an asymmetric table's cross-talk stays below the quantiser's floor, or no pairs)
         r = 1;
         if (m.nframes >= 16) {
           if (m.fast_mode) r = launch_stft_fast(m, c->stream);
@@ -720,6 +743,7 @@ static int transform(sono_ctx* c, const void* pcm, uint64_t L, void* out, uint64
   p.mw_ok = c->mw_ok ? 1u : 0u;
   p.pair_exact = c->pair_exact ? 1u : 0u;
   p.pair_asym = c->pair_asym;
+  p.pair_idx_ok = c->pair_idx_ok ? 1u : 0u;
   p.fb_bin = c->d_fb_bin;
   p.fb_w0 = c->d_fb_w;
   p.fb_w1 = c->d_fb_w ? c->d_fb_w + n / 2 : nullptr;

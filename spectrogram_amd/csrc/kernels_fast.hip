@@ -377,7 +377,7 @@ static bool fast_base_available(const StftParams& p) {
 }
 
 bool fast_u8_available(const StftParams& p) {
-  if (!fast_base_available(p)) return false;
+  if (!fast_base_available(p) || !p.pair_idx_ok) return false;
   if ((p.bin_lo & 3) || (p.bin_hi & 3) || (p.out_bins & 3) || (p.out_bin0 & 3)) return false;
   return true;
 }
@@ -394,7 +394,7 @@ bool fast_features_available(const StftParams& p) {
 // The fused image output needs the flipped full-height row mapping (any band: rows outside it are masked) and store
 // offsets (a few image rows) that fit 32 bits.
 bool fast_rgba_available(const StftParams& p) {
-  if (!fast_base_available(p)) return false;
+  if (!fast_base_available(p) || !p.pair_idx_ok) return false;
   if (p.bin_lo >= p.bin_hi) return false;
   if (p.row_of_bin0 != (int32_t)p.bin_hi - 1) return false;
   if (p.width == 0 || p.width > ((uint64_t)1 << 24) || !p.lut) return false;
@@ -409,6 +409,7 @@ int launch_stft_fast(const StftParams& p, void* stream_v) {
   using namespace fast1024;
   const bool rgba = p.out_kind == SONO_OUT_RGBA8, feat = p.out_kind == SONO_OUT_FEATURES;
   const bool flt = p.out_kind == SONO_OUT_F32_DB || p.out_kind == SONO_OUT_F32_MAG;
+  if ((rgba || p.out_kind == SONO_OUT_U8_INDEX) && !p.pair_idx_ok) return 1;  // two frames per transform: see StftParams::pair_idx_ok
   if (rgba) {
     if (!fast_rgba_available(p)) return 1;
     return launch_stft_fast_rgba(p, stream_v);  // the image writer is a kernel of its own (kernels_fast_rgba.hip)

@@ -659,14 +659,14 @@ bool fast2048_available(const StftParams& p) {
   if (!((p.fast_mode == 1 && p.fast_table) || (p.fast_mode == 2 && p.twiddles))) return false;
   if ((p.bin_lo & 3) || (p.bin_hi & 3) || p.bin_lo >= p.bin_hi) return false;
   if (p.out_kind == SONO_OUT_FEATURES) return true;
-  if (p.out_kind != SONO_OUT_U8_INDEX) return false;
+  if (p.out_kind != SONO_OUT_U8_INDEX || !p.pair_idx_ok) return false;
   return !(p.out_bins & 3) && !(p.out_bin0 & 3) && !(reinterpret_cast<uintptr_t>(p.out) & 3);
 }
 
 // The image output needs the flipped full-height row mapping, a colour table and the scratch
 // buffer (fast_rgba_scratch_bytes()).
 bool fast2048_rgba_available(const StftParams& p) {
-  if (p.n != 2048 || p.nframes < 2) return false;
+  if (p.n != 2048 || p.nframes < 2 || !p.pair_idx_ok) return false;
   if (!((p.fast_mode == 1 && p.fast_table) || (p.fast_mode == 2 && p.twiddles))) return false;
   if (p.bin_lo >= p.bin_hi) return false;
   if (p.row_of_bin0 != (int32_t)p.bin_hi - 1) return false;
@@ -675,6 +675,7 @@ bool fast2048_rgba_available(const StftParams& p) {
 
 // Returns 1 if this launch is not served here.
 int launch_stft_fast2048(const StftParams& p, void* stream_v) {
+  if ((p.out_kind == SONO_OUT_RGBA8 || p.out_kind == SONO_OUT_U8_INDEX) && !p.pair_idx_ok) return 1;  // two frames per transform: see StftParams::pair_idx_ok
   using namespace fast2048;
   const bool rgba = p.out_kind == SONO_OUT_RGBA8;
   if (rgba ? !(fast2048_rgba_available(p) && p.tile_scratch) : !fast2048_available(p)) return 1;

@@ -322,7 +322,7 @@ __global__ __launch_bounds__((1 << LOG2N) / 16 * G, 4) void stft_mw_kernel(StftP
 }  // namespace mw
 
 bool mw_u8_available(const StftParams& p) {
-  if ((p.n != 512 && p.n != 2048 && p.n != 4096) || !p.mw_ok || !p.twiddles) return false;
+  if ((p.n != 512 && p.n != 2048 && p.n != 4096) || !p.mw_ok || !p.twiddles || !p.pair_idx_ok) return false;
   if ((p.bin_lo & 3) || (p.bin_hi & 3) || (p.out_bins & 3) || (p.out_bin0 & 3)) return false;
   if (p.nframes < 2) return false;
   return true;
@@ -334,6 +334,7 @@ int launch_stft_mw(const StftParams& p, void* stream_v) {
   const bool flt = p.out_kind == SONO_OUT_F32_DB || p.out_kind == SONO_OUT_F32_MAG;
   if (!(u8 || feat || flt)) return 1;
   if (flt && !p.pair_exact) return 1;  // two frames per transform: see StftParams::pair_exact
+  if (u8 && !p.pair_idx_ok) return 1;  // ... and StftParams::pair_idx_ok
   if (feat) {  // features do not use the output row layout
     if ((p.n != 512 && p.n != 2048 && p.n != 4096) || !p.mw_ok || !p.twiddles || (p.bin_lo & 3) || (p.bin_hi & 3) ||
         p.bin_lo >= p.bin_hi || p.nframes < 2)

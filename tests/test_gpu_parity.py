@@ -655,7 +655,9 @@ def test_plugin_scaled_get_frequencies(case):
 @pytest.mark.parametrize("scale", ["mel", "logarithmic"])
 def test_scaled_frequencies_stay_on_the_float32_kernels(n, hop, scale):
     """A non-linear frequency scale in the float32 arithmetic: magnitudes from the fast transform kernels, then the
-    filter-bank kernel; the general kernel is not involved.  Indices within 1 LSB of the checker's, the image is the
+    filter-bank kernel; the general kernel is not involved -- except at 4096 points, where the only fast kernel with a
+    magnitude output transforms two frames at once and the recurrence factors would let a full-scale frame leave a
+    trace above the display floor in its partner.  Indices within 1 LSB of the checker's, the image is the
     colour map applied to the same arithmetic's indices (any band), and a NaN sample turns every bin of the frames it
     touches into index 0."""
     rng = np.random.default_rng(n + 5)
@@ -670,7 +672,7 @@ def test_scaled_frequencies_stay_on_the_float32_kernels(n, hop, scale):
         eng.set_filterbank(*fb)
         got = eng.stft(x)
         route = eng.kernel_route()
-    assert "general" not in route and "filterbank_index_kernel" in route, route
+    assert ("general" not in route or n == 4096) and "filterbank_index_kernel" in route, route
     d = cyc_diff(got, ref)
     assert got.shape == ref.shape and d.max() <= 1 and (d != 0).mean() < 0.02, (d.max(), (d != 0).mean())
     lut = (np.arange(1024, dtype=np.uint32) * 5 % 256).astype(np.uint8)
@@ -680,7 +682,7 @@ def test_scaled_frequencies_stay_on_the_float32_kernels(n, hop, scale):
         eng.set_colormap(lut)
         img = eng.stft(x)
         route = eng.kernel_route()
-    assert "general" not in route and "colorize_kernel" in route, route
+    assert ("general" not in route or n == 4096) and "colorize_kernel" in route, route
     assert np.array_equal(img, lut.reshape(256, 4)[got[:, lo:hi].T[::-1]])
     xn = x.copy()
     xn[n + 5 * hop + 17] = np.nan

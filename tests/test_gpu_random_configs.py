@@ -43,8 +43,16 @@ def draw_config(rng):
     else:
         lo = int(rng.integers(0, bins - 8))
         hi = int(rng.integers(lo + 5, bins + 1))
-    return dict(n=n, hop=hop, path=path, out=out, L=n + hop * (frames - 1) + extra, lo=lo, hi=hi,
-                i16=bool(rng.random() < 0.3), exact=bool(rng.random() < 0.15))
+    c = dict(n=n, hop=hop, path=path, out=out, L=n + hop * (frames - 1) + extra, lo=lo, hi=hi,
+             i16=bool(rng.random() < 0.3), exact=bool(rng.random() < 0.15), window="hann", alpha=None, gain=20.0, range=80.0)
+    if path == "plugin":                                   # the plugin's other options (the worker ignores them)
+        c["window"] = str(rng.choice(list(oracle.WINDOW_IDS)))
+        if c["window"] in ("blackman", "gauss") and rng.random() < 0.5:
+            c["alpha"] = float(rng.choice([0.16, 0.25, 0.4]))
+        c["gain"], c["range"] = [(20.0, 80.0), (0.0, 100.0), (40.0, 60.0), (-10.0, 30.0), (20.0, 100.0)][int(rng.integers(0, 5))]
+        if rng.random() < 0.2 and not c["exact"]:
+            c["out"] = "db"                                # float32 decibels, [frame][bin]
+    return c
 
 
 def signal(rng, L):
@@ -64,8 +72,9 @@ def engine_of(c, out_kind):
     if c["path"] == "worker":
         return E.Engine(window_id=F.WIN_WORKER_HANN, scale_mode=F.SCALE_WORKER_LOG5, frame_rule=F.FRAMES_WORKER_COMPAT,
                         twiddle_mode=F.TW_ACCURATE, **kw)
-    return E.Engine(window_id=F.WINDOW_IDS["hann"], gain_db=20.0, range_db=80.0, scale_mode=F.SCALE_PLUGIN_DB,
-                    frame_rule=F.FRAMES_PLUGIN_STRICT, twiddle_mode=F.TW_PLUGIN_RECURRENCE, **kw)
+    return E.Engine(window_id=F.WINDOW_IDS[c.get("window", "hann")], alpha=c.get("alpha") or 0.0, gain_db=c.get("gain", 20.0),
+                    range_db=c.get("range", 80.0), scale_mode=F.SCALE_PLUGIN_DB, frame_rule=F.FRAMES_PLUGIN_STRICT,
+                    twiddle_mode=F.TW_PLUGIN_RECURRENCE, **kw)
 
 
 @pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("SONO_RANDOM_CASES", "48"))))
@@ -86,7 +95,8 @@ def test_random_configuration_against_checker(seed):
         ref_img, ref_idx = oracle.worker_render(x, n, pct, LUT, want_index=True)
         mags = None
     else:
-        ref_idx, mags, _, _ = oracle.plugin_get_frequencies(x, n, n - hop, want_mags=True)
+        ref_idx, mags, _, _ = oracle.plugin_get_frequencies(x, n, n - hop, window=c["window"], alpha=c["alpha"],
+                                                            gain_db=c["gain"], range_db=c["range"], want_mags=True)
         ref_img = None
     if c["out"] == "features" and c["path"] == "worker":
         mags, _ = oracle.worker_magnitudes(x, n, hop, ref_idx.shape[0])
@@ -118,6 +128,18 @@ def test_random_configuration_against_checker(seed):
             assert np.array_equal(got, LUT.reshape(256, 4)[gi]), tag           # every pixel is an entry of the table
             d = cyc_diff(gi, wi) if c["path"] == "plugin" else np.abs(gi - wi)
             assert d.max(initial=0) <= 1 and (d != 0).mean() < 0.02, tag
+    elif c["out"] == "db":
+        with engine_of(c, F.OUT_F32_DB) as eng:
+            got = eng.stft(x_in)
+        # float32 decibels within 0.01 dB of the reference arithmetic above the display floor (-gain-range), for the
+        # bins within 75 dB of the frame's peak: float32 round-off sits about 135 dB below the peak (2e-7 of it), and
+        # 0.01 dB is a relative error of 1.2e-3
+        refd = mags[:, lo:hi].astype(np.float64)
+        assert got.shape == refd.shape, tag
+        peak = mags.astype(np.float64).max(axis=1, keepdims=True)
+        vis = (refd > 10 ** ((-c["gain"] - c["range"]) / 20)) & (refd > peak * 10 ** (-75 / 20))
+        if vis.any():
+            assert np.abs(got[vis] - 20 * np.log10(refd[vis])).max() <= 0.01, tag
     else:
         with engine_of(c, F.OUT_FEATURES) as eng:
             ft = eng.stft(x_in)
@@ -161,3 +183,86 @@ def test_features_of_silent_frames_beside_loud_ones(n, path):
         assert len(ft) == len(want_bin) and np.array_equal(ft["peak_bin"], want_bin), (n, path, lo, hi)
         assert np.array_equal(ft["peak_idx"], ref_idx[np.arange(len(want_bin)), want_bin]), (n, path, lo, hi)
         assert redone >= blocks // 4, (n, path, lo, hi, redone)     # silent frames beside loud ones were recomputed
+
+
+@pytest.mark.parametrize("n", [512, 1024, 2048, 4096])
+@pytest.mark.parametrize("out", ["u8", "rgba", "features"])
+def test_device_pointers_at_odd_offsets(n, out):
+    """Callers hand over device pointers of any alignment the element type allows (a view into a longer recording,
+    an image inside a larger buffer): samples at any 4-byte (float32) / 2-byte (int16) offset, colour indices at any
+    byte, pixels at any 4 bytes, feature records at any 8 bytes.  The kernels that need wider alignment must step
+    aside; the result is held to the checker like that of the host-pointer call (indices within 1 LSB, feature records
+    equal), and the bytes around the output stay untouched."""
+    rng = np.random.default_rng(n + len(out))
+    hop = n // 4
+    L = n + hop * 333 + 5
+    x = signal(rng, L)
+    kinds = {"u8": F.OUT_U8_INDEX, "rgba": F.OUT_RGBA8, "features": F.OUT_FEATURES}
+    out_step = {"u8": 1, "rgba": 4, "features": 8}[out]
+    for i16 in (False, True):
+        xin = np.round(x * 32767).astype(np.int16) if i16 else x
+        xval = (xin.astype(np.float32) / np.float32(32768.0)) if i16 else x
+        ref_idx = oracle.plugin_get_frequencies(xval, n, n - hop)
+        c = dict(n=n, hop=hop, path="plugin", lo=0, hi=n // 2, i16=i16, exact=False)
+        with engine_of(c, kinds[out]) as eng:
+            if out == "rgba":
+                eng.set_colormap(LUT)
+            want = eng.stft(xin)
+            nbytes = want.nbytes
+            guard = 64
+            for s_off, o_off in ((1, out_step), (2, 3 * out_step), (3, 0), (5, 5 * out_step)):
+                dpcm = eng.device_malloc(xin.nbytes + 64)
+                dout = eng.device_malloc(nbytes + 2 * guard + 64)
+                try:
+                    eng.copy_to_device(dpcm + s_off * xin.itemsize, xin)
+                    fill = np.full(nbytes + 2 * guard + 64, 0xA5, np.uint8)
+                    eng.copy_to_device(dout, fill)
+                    eng.stft_device(dpcm + s_off * xin.itemsize, L, dout + guard + o_off, nbytes)
+                    back = eng.copy_to_host(np.empty_like(fill), dout)
+                finally:
+                    eng.device_free(dpcm)
+                    eng.device_free(dout)
+                tag = (n, out, i16, s_off, o_off)
+                assert (back[:guard + o_off] == 0xA5).all() and (back[guard + o_off + nbytes:] == 0xA5).all(), tag
+                got = back[guard + o_off:guard + o_off + nbytes].view(want.dtype).reshape(want.shape)
+                if out == "features":
+                    assert np.array_equal(got["peak_bin"], want["peak_bin"]) and np.array_equal(got["peak_idx"], want["peak_idx"]), tag
+                elif out == "u8":
+                    assert cyc_diff(got, ref_idx).max() <= 1 and cyc_diff(want, ref_idx).max() <= 1, tag
+                else:
+                    assert np.array_equal(got, LUT.reshape(256, 4)[_INV[got[..., 0]]]), tag
+                    assert cyc_diff(_INV[got[..., 0]], ref_idx.T[::-1]).max() <= 1, tag
+                    assert cyc_diff(_INV[want[..., 0]], ref_idx.T[::-1]).max() <= 1, tag
+
+
+@pytest.mark.parametrize("n", [512, 1024, 2048, 4096])
+def test_full_scale_burst_beside_silence_at_low_display_floors(n):
+    """The float32 arithmetic resolves about 100 dB below the loudest value of a transform; with the plugin's recurrence
+    factors two frames share a transform, so a full-scale burst leaves a trace of about -100 dB in a silent partner.
+    The reference's defaults (gain 20, range 80: floor -100 dB) and every floor down to -100 dB stay within 1 LSB;
+    a context with a lower floor computes in the exact arithmetic and is bit-identical."""
+    hop = n // 2
+    blocks = 24
+    x = np.zeros(2 * n * blocks + 8, np.float32)
+    t = np.arange(2 * n, dtype=np.float64)
+    for b in range(0, blocks, 2):
+        x[2 * n * b:2 * n * (b + 1)] = (0.95 * np.sin(2 * np.pi * (n // 8 + 0.37) / n * t)).astype(np.float32)
+    for gain, rng_db in ((20.0, 80.0), (0.0, 100.0), (20.0, 100.0), (20.0, 120.0)):
+        ref = oracle.plugin_get_frequencies(x, n, n - hop, gain_db=gain, range_db=rng_db)
+        c = dict(n=n, hop=hop, path="plugin", lo=0, hi=n // 2, i16=False, exact=False, gain=gain, range=rng_db)
+        for s_off in (0, 1):                                   # 1: a pointer the 16-byte sample loads cannot take
+            with engine_of(c, F.OUT_U8_INDEX) as eng:
+                dpcm = eng.device_malloc(x.nbytes + 64)
+                dout = eng.device_malloc(ref.nbytes + 64)
+                try:
+                    eng.copy_to_device(dpcm + 4 * s_off, x)
+                    eng.stft_device(dpcm + 4 * s_off, len(x), dout, ref.nbytes)
+                    got = eng.copy_to_host(np.empty(ref.nbytes, np.uint8), dout).reshape(ref.shape)
+                    route = eng.kernel_route()
+                finally:
+                    eng.device_free(dpcm)
+                    eng.device_free(dout)
+            if gain + rng_db > 100.0:
+                assert np.array_equal(got, ref) and ("exact" in route or "double" in route), (n, gain, rng_db, s_off, route)
+            else:
+                assert cyc_diff(got, ref).max() <= 1, (n, gain, rng_db, s_off, route)
