@@ -266,3 +266,42 @@ def test_full_scale_burst_beside_silence_at_low_display_floors(n):
                 assert np.array_equal(got, ref) and ("exact" in route or "double" in route), (n, gain, rng_db, s_off, route)
             else:
                 assert cyc_diff(got, ref).max() <= 1, (n, gain, rng_db, s_off, route)
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_resample_and_colour_steps(seed):
+    """The steps behind getFrequencies with random shapes: resample (spectrogram.esm.js:595-640) to any width -- fewer,
+    equal, more columns, one column, one frame -- bit-identical to the checker, any window of its columns equal to the
+    same columns of the whole, and the colour-map step (:366-376) over any row window equal to the table applied to
+    the flipped indices."""
+    rng = np.random.default_rng(7000 + seed)
+    Fr = int(rng.choice([1, 2, int(rng.integers(3, 60)), int(rng.integers(60, 900))]))
+    B = int(rng.choice([1, 7, 64, 256, 512, 1120, 2048]))
+    W = int(rng.choice([1, Fr, max(1, Fr // 2), 2 * Fr + 1, int(rng.integers(1, 1500))]))
+    frames = rng.integers(0, 256, (Fr, B)).astype(np.uint8)
+    if rng.random() < 0.3:
+        frames[rng.integers(0, Fr)] = 255                                        # a saturated frame
+    want = oracle.plugin_resample(frames, W)
+    with E.Engine() as eng:
+        got = eng.resample(frames, W)
+        assert np.array_equal(got, want), (Fr, B, W)
+        # a window of columns, device to device
+        col0 = int(rng.integers(0, W))
+        ncols = int(rng.integers(1, W - col0 + 1))
+        din = eng.device_malloc(frames.nbytes)
+        dout = eng.device_malloc(ncols * B + 16)
+        try:
+            eng.copy_to_device(din, frames)
+            eng.resample_cols_device(din, Fr, B, W, col0, ncols, dout)
+            part = eng.copy_to_host(np.empty((ncols, B), np.uint8), dout)
+        finally:
+            eng.device_free(din)
+            eng.device_free(dout)
+        assert np.array_equal(part, want[col0:col0 + ncols]), (Fr, B, W, col0, ncols)
+        # colour map over a row window: image row r shows bin B - 1 - r
+        eng.set_colormap(LUT)
+        row0 = int(rng.integers(0, B))
+        rows = int(rng.integers(1, B - row0 + 1))
+        img = eng.colorize(want, row0, rows)
+        full = LUT.reshape(256, 4)[want.T[::-1]]
+        assert np.array_equal(img, full[row0:row0 + rows]), (Fr, B, W, row0, rows)

@@ -90,6 +90,34 @@ def test_merge_calls_applies_min_frames_after_stitching():
     assert len(sharding.merge_calls(lossy)) == 1
 
 
+@pytest.mark.parametrize("seed", range(40))
+def test_random_spans_reproduce_the_whole_segmentation(seed):
+    """Any cut of a recording into contiguous spans, segmented span by span (minimum run length 1) and merged with the
+    real minimum, gives the whole-recording segmentation byte for byte: runs of every length across every kind of
+    boundary, spans of one frame, empty spans, thresholds that select nothing or everything."""
+    rng = np.random.default_rng(4000 + seed)
+    n = int(rng.integers(1, 400))
+    f = np.zeros(n, F.FEATURE_DTYPE)
+    f["peak_bin"] = rng.integers(0, 512, n)
+    # runs of loud frames of random length between gaps of random length
+    level = np.zeros(n, np.int64)
+    i = 0
+    while i < n:
+        gap, run = int(rng.integers(0, 12)), int(rng.integers(1, 15))
+        level[i + gap:i + gap + run] = rng.integers(90, 256, min(run, max(0, n - i - gap)))
+        i += gap + run
+    f["peak_idx"] = level
+    threshold = int(rng.choice([0, 1, 100, 150, 255]))
+    min_frames = int(rng.integers(1, 7))
+    whole = E.segment_calls(f, threshold, min_frames)
+    cuts = sorted(set(int(c) for c in rng.integers(0, n + 1, int(rng.integers(0, 9)))) | {0, n})
+    if rng.random() < 0.3:
+        cuts = sorted(cuts + [cuts[len(cuts) // 2]])          # an empty span
+    parts = [E.segment_calls(f[a:b], threshold, 1, first_frame=a) for a, b in zip(cuts[:-1], cuts[1:])]
+    merged = sharding.merge_calls(parts, min_frames=min_frames)
+    assert merged.tobytes() == whole.tobytes(), (n, threshold, min_frames, cuts)
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
