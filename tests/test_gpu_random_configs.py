@@ -52,6 +52,9 @@ def draw_config(rng):
         c["gain"], c["range"] = [(20.0, 80.0), (0.0, 100.0), (40.0, 60.0), (-10.0, 30.0), (20.0, 100.0)][int(rng.integers(0, 5))]
         if rng.random() < 0.2 and not c["exact"]:
             c["out"] = "db"                                # float32 decibels, [frame][bin]
+        elif c["out"] in ("u8", "rgba") and rng.random() < 0.25:
+            c["scale"] = str(rng.choice(["mel", "logarithmic", "bark", "erb"]))      # a non-linear frequency scale
+            c["rate"] = int(rng.choice([44100, 256000, 384000, 500000]))
     return c
 
 
@@ -72,9 +75,12 @@ def engine_of(c, out_kind):
     if c["path"] == "worker":
         return E.Engine(window_id=F.WIN_WORKER_HANN, scale_mode=F.SCALE_WORKER_LOG5, frame_rule=F.FRAMES_WORKER_COMPAT,
                         twiddle_mode=F.TW_ACCURATE, **kw)
-    return E.Engine(window_id=F.WINDOW_IDS[c.get("window", "hann")], alpha=c.get("alpha") or 0.0, gain_db=c.get("gain", 20.0),
-                    range_db=c.get("range", 80.0), scale_mode=F.SCALE_PLUGIN_DB, frame_rule=F.FRAMES_PLUGIN_STRICT,
-                    twiddle_mode=F.TW_PLUGIN_RECURRENCE, **kw)
+    eng = E.Engine(window_id=F.WINDOW_IDS[c.get("window", "hann")], alpha=c.get("alpha") or 0.0, gain_db=c.get("gain", 20.0),
+                   range_db=c.get("range", 80.0), scale_mode=F.SCALE_PLUGIN_DB, frame_rule=F.FRAMES_PLUGIN_STRICT,
+                   twiddle_mode=F.TW_PLUGIN_RECURRENCE, **kw)
+    if "scale" in c:
+        eng.set_filterbank(*E.filterbank_table(c["scale"], c["n"], c["rate"]))
+    return eng
 
 
 @pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("SONO_RANDOM_CASES", "48"))))
@@ -94,6 +100,10 @@ def test_random_configuration_against_checker(seed):
         assert E.worker_hop(n, pct) == hop
         ref_img, ref_idx = oracle.worker_render(x, n, pct, LUT, want_index=True)
         mags = None
+    elif "scale" in c:
+        ref_idx = oracle.plugin_get_frequencies_scaled(x, n, n - hop, c["scale"], c["rate"], window=c["window"], alpha=c["alpha"],
+                                                       gain_db=c["gain"], range_db=c["range"])
+        ref_img = mags = None
     else:
         ref_idx, mags, _, _ = oracle.plugin_get_frequencies(x, n, n - hop, window=c["window"], alpha=c["alpha"],
                                                             gain_db=c["gain"], range_db=c["range"], want_mags=True)
