@@ -315,3 +315,51 @@ def test_random_resample_and_colour_steps(seed):
         img = eng.colorize(want, row0, rows)
         full = LUT.reshape(256, 4)[want.T[::-1]]
         assert np.array_equal(img, full[row0:row0 + rows]), (Fr, B, W, row0, rows)
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_plugin_option_sets_through_the_host(seed):
+    """The wavesurfer plugin's option surface through the Python mirror of the host (the same C ABI calls as the Node
+    host): random fftSamples / noverlap (given or derived from the canvas width, spectrogram.esm.js:502-506) / window
+    / gain / range / frequency range / colour map / canvas width, against the checker's getFrequencies -> resample
+    -> crop -> draw.  Exact arithmetic: bit-identical; float32: every pixel the colour of the checker's index or a
+    neighbouring one."""
+    from spectrogram_amd.plugin import AudioBuffer, Spectrogram
+    rng = np.random.default_rng(9000 + seed)
+    n = int(rng.choice([256, 512, 1024, 2048]))
+    sr = int(rng.choice([44100, 256000, 384000, 500000]))
+    L = int(rng.integers(n + 50, 60000))
+    x = signal(rng, L)
+    width = int(rng.integers(20, 900))
+    nov = None if rng.random() < 0.4 else int(rng.choice([n // 2, 3 * n // 4, n - n // 8, int(rng.integers(1, n))]))
+    window = str(rng.choice(list(oracle.WINDOW_IDS)))
+    gain, rng_db = [(20.0, 80.0), (0.0, 100.0), (40.0, 60.0)][int(rng.integers(0, 3))]
+    fmin = float(rng.choice([0.0, rng.uniform(0, 0.2) * sr]))
+    fmax = float(rng.choice([0.0, rng.uniform(0.25, 0.5) * sr, 0.7 * sr]))            # 0: Nyquist; above Nyquist: background rows
+    cm = rng.random((256, 4))
+    exact = bool(rng.random() < 0.4)
+    opts = {"fftSamples": n, "colorMap": cm.tolist(), "scale": "linear", "frequencyMin": fmin, "frequencyMax": fmax,
+            "windowFunc": window, "gainDB": gain, "rangeDB": rng_db, "arith": "exact" if exact else "fast"}
+    if nov is not None:
+        opts["noverlap"] = nov
+    p = Spectrogram.create(opts)
+    try:
+        buf = AudioBuffer(x, sr)
+        frames = p.getFrequencies(buf, canvas_width=width)[0]
+        ref_frames = oracle.plugin_get_frequencies(x, n, nov, canvas_width=width, window=window, gain_db=gain, range_db=rng_db)
+        tag = (n, sr, L, width, nov, window, gain, rng_db, fmin, fmax, exact)
+        assert frames.shape == ref_frames.shape, tag
+        lut = oracle.plugin_lut(cm)
+        assert np.array_equal(p._colorMapUint, lut), tag
+        if exact:
+            assert np.array_equal(frames, ref_frames), tag
+        else:
+            d = cyc_diff(frames, ref_frames)
+            assert d.max(initial=0) <= 1 and (d != 0).mean() < 0.02, tag
+        # resample + draw from the host's own frames (so that the float32 case is compared step by step)
+        rgba, (sy, sh) = p.drawSpectrogram(frames, width)
+        want = oracle.plugin_draw(oracle.plugin_resample(frames, width), lut)
+        assert np.array_equal(rgba, want), tag
+        assert (sy, sh) == oracle.plugin_crop(n // 2, sr, fmin, fmax if fmax else sr / 2), tag
+    finally:
+        p.destroy()
