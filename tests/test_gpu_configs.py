@@ -340,3 +340,95 @@ def test_device_numa_node_and_binding():
         assert os.sched_getaffinity(0) <= before and os.sched_getaffinity(0)
     finally:
         os.sched_setaffinity(0, before)
+
+
+def test_recording_beyond_32_bit_sample_offsets():
+    """A recording of more than 2^32 samples (3.7 h at 384 kHz, int16, 10 GB in device memory; 19.9 M frames, an image
+    wider than 2^24 columns): sample offsets, frame numbers times the hop, output offsets and the image's row pitch
+    all pass 32 bits.  Periodic signal, so: feature records and colour indices repeat every 64 frames and their heads
+    are the checker's; the worker image is the colour map applied to the index output of the same arithmetic, flipped
+    and transposed, in every column."""
+    torch = pytest.importorskip("torch")
+    n, hop, period_frames = 1024, 256, 64
+    period = hop * period_frames
+    L = (1 << 32) + 3 * (1 << 28) + 12345
+    rng = np.random.default_rng(13)
+    base = rng.standard_normal(period) * 0.05
+    base[5000:9000] += 0.5 * np.sin(np.arange(4000) * 0.8 + 1e-4 * np.arange(4000) ** 2)
+    q = np.round(np.clip(base, -1, 1) * 32767).astype(np.int16)
+    dev = torch.device("cuda:0")
+    x = torch.from_numpy(q).to(dev).repeat(L // period + 1)[:L].contiguous()
+    head_pcm = (np.tile(q, 3)[:2 * period + n + 1].astype(np.float32) / np.float32(32768.0))
+    ref_idx, ref_mag, _, _ = oracle.plugin_get_frequencies(head_pcm, n, n - hop, want_mags=True)
+    # feature records (plugin path)
+    with plugin_engine(n, hop, out_kind=F.OUT_FEATURES, in_kind=F.IN_I16) as eng:
+        g = eng.geometry(L)
+        assert g.frames == (L - n + hop - 1) // hop > (1 << 24)
+        ft = torch.empty((g.frames, 8), dtype=torch.uint8, device=dev)
+        eng.stft_device(x.data_ptr(), L, ft.data_ptr(), ft.numel())
+        whole = (g.frames // period_frames) * period_frames
+        rec = ft[:whole, :5].view(-1, period_frames, 5)                    # peak_bin (4 bytes) + peak_idx
+        assert bool((rec == rec[0:1]).all())
+        head = ft[:period_frames].cpu().numpy().view(F.FEATURE_DTYPE).reshape(-1)
+        tail = ft[g.frames - 3:].cpu().numpy().view(F.FEATURE_DTYPE).reshape(-1)
+    want_bin = oracle.frame_peaks_f32(ref_mag[:period_frames])
+    assert np.array_equal(head["peak_bin"], want_bin)
+    assert np.array_equal(head["peak_idx"], ref_idx[np.arange(period_frames), want_bin])
+    k = (g.frames - 3) % period_frames                                    # the last frames, past the whole periods
+    assert np.array_equal(tail["peak_bin"], np.resize(want_bin, k + 3 + period_frames)[k:k + 3])
+    del ft, rec
+    # colour indices and the image (worker path)
+    lut = (np.arange(1024, dtype=np.uint32) * 13 % 251).astype(np.uint8)
+    with worker_engine(n, hop, out_kind=F.OUT_RGBA8, in_kind=F.IN_I16) as eng, \
+            worker_engine(n, hop, out_kind=F.OUT_U8_INDEX, in_kind=F.IN_I16) as eng8:
+        eng.set_colormap(lut)
+        g = eng.geometry(L)
+        assert g.width > (1 << 24) and g.bins == 512
+        idx = torch.empty((g.frames, g.bins), dtype=torch.uint8, device=dev)
+        eng8.stft_device(x.data_ptr(), L, idx.data_ptr(), idx.numel())
+        whole = (g.frames // period_frames) * period_frames
+        v = idx[:whole].view(-1, period_frames, g.bins)
+        assert bool((v == v[0:1]).all())
+        head8 = idx[:period_frames].cpu().numpy()
+        img = torch.empty((g.bins, g.width, 4), dtype=torch.uint8, device=dev)
+        eng.stft_device(x.data_ptr(), L, img.data_ptr(), img.numel())
+        route = eng.kernel_route()
+        px = img.view(torch.int32).view(g.bins, g.width)
+        lut32 = torch.from_numpy(lut.view(np.int32).copy()).to(dev)
+        for c0 in range(1, g.width, 1 << 18):                                # (column 0 may hold the wrapped last frame)
+            c1 = min(g.width, c0 + (1 << 18))
+            want = lut32[idx[c0:c1].long()].t().flip(0)
+            assert bool((px[:, c0:c1] == want).all()), (c0, route)
+    refw = oracle.worker_render(head_pcm, n, 75.0, None, want_index=True)[1]
+    assert np.abs(head8.astype(np.int16) - refw[:period_frames]).max() <= 1
+
+
+@pytest.mark.parametrize("n,hop", [(512, 128), (2048, 512), (4096, 1024), (4096, 1022)])
+def test_other_sizes_beyond_32_bit_sample_offsets(n, hop):
+    """The same at the other transform sizes (their own kernels; hop 1022 at 4096 points is the general kernel): colour
+    indices of a periodic float32 recording of more than 2^32 samples repeat every period and start like the checker's."""
+    torch = pytest.importorskip("torch")
+    period_frames = 64
+    period = hop * period_frames
+    L = (1 << 32) + (1 << 27) + 4321
+    rng = np.random.default_rng(n + hop)
+    base = (rng.standard_normal(period) * 0.05).astype(np.float32)
+    base[period // 3:period // 2] += (0.5 * np.sin(np.arange(period // 2 - period // 3) * 0.6)).astype(np.float32)
+    dev = torch.device("cuda:0")
+    x = torch.from_numpy(base).to(dev).repeat(L // period + 1)[:L].contiguous()
+    with plugin_engine(n, hop) as eng:
+        g = eng.geometry(L)
+        out = torch.empty((g.frames, g.bins), dtype=torch.uint8, device=dev)
+        eng.stft_device(x.data_ptr(), L, out.data_ptr(), out.numel())
+        route = eng.kernel_route()
+        whole = (g.frames // period_frames) * period_frames
+        v = out[:whole].view(-1, period_frames, g.bins)
+        assert bool((v == v[0:1]).all()), route
+        head = out[:period_frames].cpu().numpy()
+        tail = out[g.frames - 2:].cpu().numpy()
+    ref = oracle.plugin_get_frequencies(np.tile(base, 3)[:period + n + 1 + hop], n, n - hop)[:period_frames]
+    d = np.abs(head.astype(np.int16) - ref.astype(np.int16))
+    d = np.minimum(d, 256 - d)
+    assert d.max() <= 1, route
+    k = (g.frames - 2) % period_frames
+    assert np.array_equal(tail, np.concatenate([head, head])[k:k + 2]), route
