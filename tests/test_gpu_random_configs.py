@@ -363,3 +363,48 @@ def test_random_plugin_option_sets_through_the_host(seed):
         assert (sy, sh) == oracle.plugin_crop(n // 2, sr, fmin, fmax if fmax else sr / 2), tag
     finally:
         p.destroy()
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_random_worker_messages(seed):
+    """The worker's message contract (spectrogramWorker.js:17-36) with random render messages through the Python
+    mirror of the host: fftSize, overlap percentage (any number: the hop is max(1, floor(N (1 - pct/100)))), buffer
+    lengths around a whole number of hops (the wrapped last frame), with and without a colour map, options that the
+    reference ignores.  Exact arithmetic: the checker's image byte for byte; float32: every pixel within one step."""
+    from spectrogram_amd.worker import SpectrogramWorker
+    rng = np.random.default_rng(12000 + seed)
+    n = int(rng.choice([256, 512, 1024, 2048, 4096]))
+    pct = float(rng.choice([0, 50, 75, 87.5, 93.75, round(rng.uniform(0, 99), 2)]))
+    hop = E.worker_hop(n, pct)
+    frames = int(rng.integers(2, 400))
+    L = n + hop * (frames - 1) + int(rng.choice([0, int(rng.integers(0, max(1, hop)))]))
+    x = signal(rng, L)
+    with_map = bool(rng.random() < 0.6)
+    cm = rng.random((256, 4))
+    arith = "exact" if rng.random() < 0.4 else "fast"
+    lut = E.worker_lut(cm) if with_map else None
+    want = oracle.worker_render(x, n, pct, lut)
+    got = []
+    wk = SpectrogramWorker(arith=arith)
+    wk.onmessage = lambda e: got.append(e["data"])
+    canvas = {}
+    wk.postMessage({"type": "init", "canvas": canvas, "options": {"colorMap": cm.tolist()} if with_map else {}})
+    wk.postMessage({"type": "render", "buffer": x, "fftSize": n, "overlap": pct,
+                    "options": {"windowFunc": "hamming", "gainDB": 7, "rangeDB": 33}})       # accepted, ignored
+    wk.terminate()
+    tag = (n, pct, hop, L, with_map, arith)
+    assert len(got) == 1 and got[0]["type"] == "rendered", tag
+    img = got[0]["data"]
+    assert img.shape == want.shape, tag
+    if arith == "exact":
+        assert np.array_equal(img, want), tag
+    elif not with_map:
+        assert np.abs(img[..., :3].astype(np.int16) - want[..., :3]).max() <= 1 and (img[..., 3] == 255).all(), tag
+    else:
+        # the checker's indices, and the colours of the neighbouring ones
+        idx = oracle.worker_render(x, n, pct, None)[..., 0].astype(np.int16)
+        l4 = lut.reshape(256, 4)
+        ok = np.zeros(idx.shape, bool)
+        for dlt in (-1, 0, 1):
+            ok |= np.all(img == l4[np.clip(idx + dlt, 0, 255)], axis=-1)
+        assert ok.all(), tag
