@@ -472,13 +472,13 @@ __global__ __launch_bounds__(kWaves * 64) void stft2048_kernel(StftParams p, Fas
         if (st_a) {
           sono_frame_feature r{};
           r.peak_bin = kbest_a;
-          r.peak_idx = (uint8_t)put_index<PLUGIN, 0>(best_a, fs, 0);
+          r.peak_idx = (uint8_t)(PLUGIN ? fast_plugin_peak_index(best_a, fs) : put_index<false, 0>(best_a, fs, 0));
           r.reserved[0] = (feature_uncertain(best_a, next_a, top_b, top_a, ta, fs) || peak_outside(kbest_a, p.feat_lo, p.feat_hi)) ? 1 : 0;
           ft[0] = r;
         }
         sono_frame_feature r{};
         r.peak_bin = kbest_b;
-        r.peak_idx = (uint8_t)put_index<PLUGIN, 0>(best_b, fs, 0);
+        r.peak_idx = (uint8_t)(PLUGIN ? fast_plugin_peak_index(best_b, fs) : put_index<false, 0>(best_b, fs, 0));
         r.reserved[0] = (feature_uncertain(best_b, next_b, top_a, top_b, tb, fs) || peak_outside(kbest_b, p.feat_lo, p.feat_hi)) ? 1 : 0;
         ft[1] = r;
       }

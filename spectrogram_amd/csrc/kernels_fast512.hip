@@ -394,7 +394,7 @@ __global__ __launch_bounds__(kWaves * 64) void stft512_kernel(StftParams p, Fast
           // reserved[0] = 1: float32 cannot tell; the exact-arithmetic pass that follows recomputes the record
           sono_frame_feature r{};
           r.peak_bin = kbest[i];
-          r.peak_idx = (uint8_t)put_index<PLUGIN, 0>(best[i], fs, 0);
+          r.peak_idx = (uint8_t)(PLUGIN ? fast_plugin_peak_index(best[i], fs) : put_index<false, 0>(best[i], fs, 0));
           r.reserved[0] = (feature_uncertain(best[i], next[i], seen[i ^ 1], seen[i],
                                              __builtin_fmaf(__log2f(best[i]), fs.a, fs.b), fs) ||
                            peak_outside(kbest[i], p.feat_lo, p.feat_hi)) ? 1 : 0;

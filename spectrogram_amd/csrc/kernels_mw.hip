@@ -302,14 +302,14 @@ __global__ __launch_bounds__((1 << LOG2N) / 16 * G, 4) void stft_mw_kernel(StftP
         if (st_a) {
           sono_frame_feature r{};
           r.peak_bin = kbest_a;
-          r.peak_idx = (uint8_t)put_index<PLUGIN, 0>(best_a, fs, 0);
+          r.peak_idx = (uint8_t)(PLUGIN ? fast_plugin_peak_index(best_a, fs) : put_index<false, 0>(best_a, fs, 0));
           r.reserved[0] = (feature_uncertain(best_a, next_a, top, top, ta, fs) || peak_outside(kbest_a, p.feat_lo, p.feat_hi)) ? 1 : 0;
           ft[0] = r;
         }
         if (active) {
           sono_frame_feature r{};
           r.peak_bin = kbest_b;
-          r.peak_idx = (uint8_t)put_index<PLUGIN, 0>(best_b, fs, 0);
+          r.peak_idx = (uint8_t)(PLUGIN ? fast_plugin_peak_index(best_b, fs) : put_index<false, 0>(best_b, fs, 0));
           r.reserved[0] = (feature_uncertain(best_b, next_b, top, top, tb, fs) || peak_outside(kbest_b, p.feat_lo, p.feat_hi)) ? 1 : 0;
           ft[1] = r;
         }

@@ -209,10 +209,20 @@ __device__ __forceinline__ uint32_t fast_index(float mag_sq, const FastScale& s)
 // conversion rounds to nearest (ties to even), so floor(t) is taken as round(t - 0.5): the same for every t that is not
 // an integer, and at an integer t float32 cannot tell which side of the step the reference is on anyway (the feature
 // pass marks such records and has them recomputed in the exact arithmetic).  One instruction less per bin.
+// (The plugin's magnitude floor of 1e-12 needs no instruction here: it is r = -240 dB, below -gain-range for every
+// context that computes in float32 -- those have gain + range <= 100 -- so it is index 0, and that is what the
+// saturating conversion makes of any t < 0.5, of -infinity from a zero magnitude and of a NaN, which the reference
+// sends to the floor as well.)
 template <int BYTE>
 __device__ __forceinline__ uint32_t fast_plugin_byte(float mag_sq, const FastScale& s, uint32_t acc) {
-  const float t = fmaxf(__builtin_fmaf(__log2f(mag_sq), s.a, s.b - 0.5f), s.t_floor - 0.5f);
+  const float t = __builtin_fmaf(__log2f(mag_sq), s.a, s.b - 0.5f);
   return __builtin_amdgcn_cvt_pk_u8_f32(t, BYTE, acc);
+}
+// The colour index of a frame's peak in the feature records: here the magnitude floor is kept, because a feature
+// context computes in float32 whatever its gain and range are, and with gain + range > 240 the floor is not index 0.
+__device__ __forceinline__ uint32_t fast_plugin_peak_index(float mag_sq, const FastScale& s) {
+  const float t = fmaxf(__builtin_fmaf(__log2f(mag_sq), s.a, s.b - 0.5f), s.t_floor - 0.5f);
+  return __builtin_amdgcn_cvt_pk_u8_f32(t, 0, 0u);
 }
 template <int BYTE>
 __device__ __forceinline__ uint32_t fast_worker_byte(float mag_sq, const FastScale& s, uint32_t acc) {
