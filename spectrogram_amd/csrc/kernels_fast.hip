@@ -48,6 +48,10 @@ constexpr int kWinBytes = 32 * kPlaneStride * 4;   // window as [l][kPlaneStride
 constexpr int lds_bytes(int waves) { return kTwBytes + kWinBytes + waves * 2 * kFftBufBytes; }  // 16 waves: 160256
 // HOP32 > 0: hop == 32*HOP32, so frame B's sample 32a+l is frame A's sample 32(a+HOP32)+l and one
 // run of 32+HOP32 loads feeds both frames.  HOP32 == 0: any hop, two runs of 32 loads.
+// HOP32 < 0: ONE real frame per transform (imaginary part zero), for twiddle tables under which a frame would leave
+// a visible trace in a partner (StftParams::pair_idx_ok) or float32 outputs would carry it (pair_exact): half the
+// throughput of the paired flavour, which is still several times the general kernel's.  A wavefront then handles two
+// frames per iteration, one per half.
 //
 // The image output is a kernel of its own (kernels_fast_rgba.hip).
 // OUT: kOutU8 / kOutFeatures (per-frame spectral peak: strict-> first-wins argmax of |X|^2
@@ -62,6 +66,8 @@ template <bool PLUGIN, typename In, int HOP32, int OUT, bool TABLE>
 __global__ __launch_bounds__(kMaxWaves * 64, 4) void stft1024_u8_kernel(StftParams p, FastScale fs,
                                                                         const float2* __restrict__ tw_table) {
   constexpr bool FEAT = OUT == kOutFeatures, FLT = OUT == kOutDb || OUT == kOutMag;
+  constexpr bool SINGLE = HOP32 < 0;
+  static_assert(!(SINGLE && FEAT), "the feature records come from the paired flavour (its marks cover the cross-talk)");
   constexpr int kThreads = kMaxWaves * 64, kWaves = kMaxWaves;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float2* tw_lds = reinterpret_cast<float2*>(smem);
@@ -92,7 +98,7 @@ __global__ __launch_bounds__(kMaxWaves * 64, 4) void stft1024_u8_kernel(StftPara
 
   const In* __restrict__ x = reinterpret_cast<const In*>(p.pcm);
   uint8_t* __restrict__ out = reinterpret_cast<uint8_t*>(p.out);
-  const uint64_t npairs = (p.nframes + 1) >> 1;
+  const uint64_t npairs = SINGLE ? p.nframes : (p.nframes + 1) >> 1;  // transforms
   // blocks with equal blockIdx % 8 share an XCD (and its L2): give them neighbouring frame ranges
   const uint32_t per = gridDim.x >> 3;
   const uint32_t vb = (gridDim.x & 7) ? blockIdx.x : (blockIdx.x & 7) * per + (blockIdx.x >> 3);
@@ -114,6 +120,12 @@ __global__ __launch_bounds__(kMaxWaves * 64, 4) void stft1024_u8_kernel(StftPara
       return u;
     }
     const uint64_t pair = pair0 + h;
+    if constexpr (SINGLE) {  // transform `pair` is frame `pair`; a half without a frame repeats the other half's
+      u.st_a = pair < npairs;
+      u.st_b = false;
+      u.f0 = u.st_a ? pair : pair0;
+      return u;
+    }
     u.f0 = 2 * pair;
     u.st_a = u.st_b = pair < npairs;
     if (!u.st_a) {  // this half has no pair of its own: it repeats valid frames and stores nothing
@@ -126,11 +138,14 @@ __global__ __launch_bounds__(kMaxWaves * 64, 4) void stft1024_u8_kernel(StftPara
   };
   // The samples of an iteration are loaded one iteration ahead (into raw), so that their latency overlaps with the
   // arithmetic.
-  constexpr int kRaw = HOP32 > 0 ? 32 + HOP32 : 64;
+  constexpr int kRaw = SINGLE ? 32 : HOP32 > 0 ? 32 + HOP32 : 64;
   float raw[kRaw];
   auto fetch = [&](const Unit& u) {
     const In* xa = x + (p.frame0 + u.f0) * p.hop + l;
-    if constexpr (HOP32 > 0) {
+    if constexpr (SINGLE) {
+#pragma unroll
+      for (int a = 0; a < 32; ++a) raw[a] = ld<In>(xa, 32 * a);
+    } else if constexpr (HOP32 > 0) {
 #pragma unroll
       for (int a = 0; a < 32 + HOP32; ++a) raw[a] = ld<In>(xa, 32 * a);
     } else {
@@ -147,7 +162,7 @@ __global__ __launch_bounds__(kMaxWaves * 64, 4) void stft1024_u8_kernel(StftPara
   for (uint64_t it = 0; cur.active; ++it) {
     const Unit nxt = locate(it + 1);
     const uint64_t f0 = cur.f0;
-    const bool st_a = cur.st_a, st_b = cur.st_b;
+    const bool st_a = cur.st_a, st_b = SINGLE ? false : cur.st_b;
 
     float re[32], im[32];
     {
@@ -160,7 +175,7 @@ __global__ __launch_bounds__(kMaxWaves * 64, 4) void stft1024_u8_kernel(StftPara
 #pragma unroll
       for (int a = 0; a < 32; ++a) {
         re[brev5(a)] = raw[a] * win[a];
-        im[brev5(a)] = raw[a + (HOP32 > 0 ? HOP32 : 32)] * win[a];
+        im[brev5(a)] = SINGLE ? 0.0f : raw[SINGLE ? a : a + (HOP32 > 0 ? HOP32 : 32)] * win[a];
       }
     }
     // first pass; then (exact roots only) the twiddle W_1024^(l*k1); then transpose lane l, register
@@ -223,7 +238,9 @@ __global__ __launch_bounds__(kMaxWaves * 64, 4) void stft1024_u8_kernel(StftPara
     // mbuf[0] (Z[N - 256P] = Z[0] or Z[768]).
     const uint64_t row_a = (p.col0 + f0) * p.out_bins, row_b = row_a + p.out_bins;
     // FLT: the pair separation leaves 2*X; the plugin's magnitude is 2/N * |X| (spectrogram.esm.js:195-198)
-    const float mag_scale = PLUGIN ? 1.0f / (float)kNPoints : 0.5f;
+    // (one frame per transform: its spectrum is Z itself -- the reference's own transform of the frame, the table's
+    // asymmetry included -- so there is no partner to read and no factor 2)
+    const float mag_scale = SINGLE ? (PLUGIN ? 2.0f / (float)kNPoints : 1.0f) : PLUGIN ? 1.0f / (float)kNPoints : 0.5f;
     float best_a = -1.0f, best_b = -1.0f;  // FEAT: this lane's largest |X|^2 so far and its bin
     float next_a = -1.0f, next_b = -1.0f;  // FEAT: ... and the runner-up (what decides whether float32 can tell)
     int kbest_a = (int)p.bin_lo, kbest_b = (int)p.bin_lo;
@@ -242,9 +259,11 @@ __global__ __launch_bounds__(kMaxWaves * 64, 4) void stft1024_u8_kernel(StftPara
         const int kl = 8 * P + r;        // Z[k1 + 32*kl]        -> lbuf[32*r + k1]
         const int km = 24 - 8 * P + r;   // Z[k1 + 32*km] = Z[N - j], j = 32*(7 - r) + 32 - k1 (+256P)
         lbuf[32 * r + l] = make_float2(re[kl], im[kl]);
-        mbuf[32 * (7 - r) + 32 - l] = make_float2(re[km], im[km]);
+        if constexpr (!SINGLE) mbuf[32 * (7 - r) + 32 - l] = make_float2(re[km], im[km]);
       }
-      if (l == 0) mbuf[0] = make_float2(re[P ? 24 : 0], im[P ? 24 : 0]);
+      if constexpr (!SINGLE) {
+        if (l == 0) mbuf[0] = make_float2(re[P ? 24 : 0], im[P ? 24 : 0]);
+      }
       wave_sync();
 #pragma unroll
       for (int g = 0; g < 2; ++g) {
@@ -252,14 +271,14 @@ __global__ __launch_bounds__(kMaxWaves * 64, 4) void stft1024_u8_kernel(StftPara
         const int k = 256 * P + idx;
         const float4 z01 = *reinterpret_cast<const float4*>(lbuf + idx);
         const float4 z23 = *reinterpret_cast<const float4*>(lbuf + idx + 2);
-        const float4 q01 = *reinterpret_cast<const float4*>(mbuf + idx);
-        const float4 q23 = *reinterpret_cast<const float4*>(mbuf + idx + 2);
+        const float4 q01 = SINGLE ? make_float4(0, 0, 0, 0) : *reinterpret_cast<const float4*>(mbuf + idx);
+        const float4 q23 = SINGLE ? make_float4(0, 0, 0, 0) : *reinterpret_cast<const float4*>(mbuf + idx + 2);
         uint32_t wa = 0, wb = 0;
         float fa[4] = {0, 0, 0, 0}, fb[4] = {0, 0, 0, 0};
         const bool in_band = k >= (int)p.bin_lo && k < (int)p.bin_hi;
 #define SONO_BIN(B, ZR, ZI, PR, PI)                                          \
   {                                                                          \
-    const float ar = (ZR) + (PR), ai = (ZI) - (PI);                          \
+    const float ar = SINGLE ? (ZR) : (ZR) + (PR), ai = SINGLE ? (ZI) : (ZI) - (PI); \
     const float br = (ZI) + (PI), bi = (PR) - (ZR);                          \
     const float ma = __builtin_fmaf(ar, ar, ai * ai);                        \
     const float mb = __builtin_fmaf(br, br, bi * bi);                        \
@@ -377,7 +396,7 @@ static bool fast_base_available(const StftParams& p) {
 }
 
 bool fast_u8_available(const StftParams& p) {
-  if (!fast_base_available(p) || !p.pair_idx_ok) return false;
+  if (!fast_base_available(p) || (!p.pair_idx_ok && p.fast_mode != 2)) return false;  // (table flavour: one frame per transform then)
   if ((p.bin_lo & 3) || (p.bin_hi & 3) || (p.out_bins & 3) || (p.out_bin0 & 3)) return false;
   return true;
 }
@@ -409,13 +428,14 @@ int launch_stft_fast(const StftParams& p, void* stream_v) {
   using namespace fast1024;
   const bool rgba = p.out_kind == SONO_OUT_RGBA8, feat = p.out_kind == SONO_OUT_FEATURES;
   const bool flt = p.out_kind == SONO_OUT_F32_DB || p.out_kind == SONO_OUT_F32_MAG;
-  if ((rgba || p.out_kind == SONO_OUT_U8_INDEX) && !p.pair_idx_ok) return 1;  // two frames per transform: see StftParams::pair_idx_ok
+  // one frame per transform where two would not do: colour indices under a table whose cross-talk could show
+  // (StftParams::pair_idx_ok), float32 outputs under any asymmetric table (StftParams::pair_exact)
+  const bool single = p.fast_mode == 2 && ((p.out_kind == SONO_OUT_U8_INDEX && !p.pair_idx_ok) || (flt && !p.pair_exact));
   if (rgba) {
     if (!fast_rgba_available(p)) return 1;
     return launch_stft_fast_rgba(p, stream_v);  // the image writer is a kernel of its own (kernels_fast_rgba.hip)
   } else if (flt) {
     if (!fast_float_available(p)) return 1;
-    if (p.fast_mode == 2 && !p.pair_exact) return 1;  // two frames per transform: see StftParams::pair_exact
   } else if (feat) {
     if (!fast_features_available(p)) return 1;
   } else {
@@ -425,11 +445,13 @@ int launch_stft_fast(const StftParams& p, void* stream_v) {
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_v);
   FastScale fs = make_fast_scale(p.scale_mode, p.n, p.gain_db, p.range_db);
   // the pair separation leaves 2*X: |2X|^2 = 4|X|^2, i.e. log2 is 2 too large
-  fs.b -= 2.0f * fs.a;
-  fs.db_off -= 2.0f * 3.0102999566f;
+  if (!single) {
+    fs.b -= 2.0f * fs.a;
+    fs.db_off -= 2.0f * 3.0102999566f;
+  }
   fs.xtalk = (float)p.pair_asym;
-  const uint64_t npairs = (p.nframes + 1) / 2;
-  const uint64_t per_wg = (uint64_t)kMaxWaves * 2;  // one wavefront handles 2 pairs per iteration
+  const uint64_t npairs = single ? p.nframes : (p.nframes + 1) / 2;  // transforms
+  const uint64_t per_wg = (uint64_t)kMaxWaves * 2;  // one wavefront handles 2 transforms per iteration
   const uint64_t need = (npairs + per_wg - 1) / per_wg;
   const int cus = device_cu_count();
   const uint32_t grid = (uint32_t)(need < (uint64_t)cus ? need : (uint64_t)cus);  // persistent: one workgroup per CU
@@ -455,7 +477,11 @@ int launch_stft_fast(const StftParams& p, void* stream_v) {
   } while (0)
 #define SONO_LAUNCH(PLUGIN, In)                                                                             \
   do {                                                                                                      \
-    if (p.hop == 256) SONO_LAUNCH_H(PLUGIN, In, 8);                                                         \
+    if (single) {                                                                                           \
+      if (p.out_kind == SONO_OUT_F32_DB) SONO_LAUNCH_T(PLUGIN, In, -1, kOutDb, true);                       \
+      else if (p.out_kind == SONO_OUT_F32_MAG) SONO_LAUNCH_T(PLUGIN, In, -1, kOutMag, true);                \
+      else SONO_LAUNCH_T(PLUGIN, In, -1, kOutU8, true);                                                     \
+    } else if (p.hop == 256) SONO_LAUNCH_H(PLUGIN, In, 8);                                                  \
     else if (p.hop == 512) SONO_LAUNCH_H(PLUGIN, In, 16);                                                   \
     else SONO_LAUNCH_H(PLUGIN, In, 0);                                                                      \
   } while (0)
@@ -469,7 +495,7 @@ int launch_stft_fast(const StftParams& p, void* stream_v) {
 #undef SONO_LAUNCH_H
 #undef SONO_LAUNCH_O
 #undef SONO_LAUNCH_T
-  note_kernel(tab ? "stft1024_u8_kernel<table>" : "stft1024_u8_kernel<roots>");
+  note_kernel(single ? "stft1024_u8_kernel<table,single>" : tab ? "stft1024_u8_kernel<table>" : "stft1024_u8_kernel<roots>");
   return hipGetLastError() == hipSuccess ? SONO_OK : SONO_ERR_DEVICE;
 }
 

@@ -412,6 +412,35 @@ def test_kernel_route_is_visible_and_default_view_is_fast():
         assert eng.kernel_route() == "stft1024_exact_kernel"
 
 
+def test_one_frame_per_transform_where_pairing_would_leak():
+    """Under the plugin's recurrence table (fft.js:149-164) two frames that share a complex transform leak into each
+    other at asymmetry x sum|w|.  A rectangular window at 1024 points puts that above the display floor of the
+    default gain / range, and float32 dB output has no floor at all: those contexts run the 1024-point kernel with
+    one real frame per transform, whose spectrum is the reference's own transform of that frame."""
+    rng = np.random.default_rng(1024)
+    L = 1024 + 256 * 700 + 3
+    x = (rng.standard_normal(L) * 1e-4).astype(np.float32)
+    x[256 * 200:256 * 200 + 1024] += 0.9 * np.sin(np.arange(1024) * 0.61).astype(np.float32)   # one loud frame span
+    ref = oracle.plugin_get_frequencies(x, 1024, 768, window="rectangular")
+    with plugin_engine(1024, 256, F.ARITH_FAST_F32, window="rectangular") as eng:
+        got = eng.stft(x)
+        assert eng.kernel_route() == "stft1024_u8_kernel<table,single>"
+    assert got.shape == ref.shape and cyc_diff(got, ref).max() <= 1
+    assert (got == ref).mean() > 0.98
+    # the Hann window at the same settings keeps the paired flavour
+    with plugin_engine(1024, 256, F.ARITH_FAST_F32) as eng:
+        eng.stft(x)
+        assert eng.kernel_route() == "stft1024_u8_kernel<table>"
+    # float32 dB under the table: single flavour, 0.01 dB where the bin is within 75 dB of its frame's peak
+    _, mags, _, _ = oracle.plugin_get_frequencies(x, 1024, 768, want_mags=True)
+    with plugin_engine(1024, 256, F.ARITH_FAST_F32, out_kind=F.OUT_F32_DB) as eng:
+        db = eng.stft(x)
+        assert eng.kernel_route() == "stft1024_u8_kernel<table,single>"
+    want = 20.0 * np.log10(np.maximum(mags.astype(np.float64), 1e-12))
+    near = mags > mags.max(axis=1, keepdims=True) * 10 ** (-75 / 20)
+    assert np.abs(db - want)[near].max() <= 0.01
+
+
 # ------------------------------------------------------------------ per-frame features (SONO_OUT_FEATURES)
 def test_features_exact_bit_exact_against_checker():
     """Integer feature indices are bit-exact: peak_bin is the strict-> first-wins argmax of the float32

@@ -34,6 +34,7 @@ int main(int argc, char** argv) {
   cfg.fft_n = fft;
   cfg.hop = hop;
   cfg.window_id = plugin ? SONO_WIN_HANN : SONO_WIN_WORKER_HANN;
+  if (plugin && getenv("SONO_BENCH_WINDOW")) cfg.window_id = (uint32_t)atoi(getenv("SONO_BENCH_WINDOW"));  // a SONO_WIN_* id
   cfg.scale_mode = plugin ? SONO_SCALE_PLUGIN_DB : SONO_SCALE_WORKER_LOG5;
   cfg.frame_rule = plugin ? SONO_FRAMES_PLUGIN_STRICT : SONO_FRAMES_WORKER_COMPAT;
   cfg.twiddle_mode = plugin ? SONO_TW_PLUGIN_RECURRENCE : SONO_TW_ACCURATE;
