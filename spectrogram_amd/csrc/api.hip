@@ -34,6 +34,8 @@ struct sono_ctx {
   bool have_lut = false;
   int32_t* d_fb_bin = nullptr;  // filter bank of a non-linear frequency scale (fft_n/2 entries each), or nullptr
   double* d_fb_w = nullptr;     // w0 then w1
+  void* d_fb_packed = nullptr;  // the same bank for the 1024-point float32 kernel: int32 tap[n/2], float w0[n/2], float w1[n/2],
+                                // taps outside the spectrum folded away (pack_filterbank)
   bool host_twiddles = false;  // sono_set_tables replaced the twiddle table
   // host copies (sono_set_tables may replace part of them)
   std::vector<float> h_window;
@@ -306,7 +308,7 @@ void sono_destroy(sono_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
-  void* bufs[] = {c->d_window, c->d_tw, c->d_tw_exact, c->d_claim, c->d_lut, c->d_fast, c->d_in, c->d_out, c->d_aux, c->d_fb_bin, c->d_fb_w};
+  void* bufs[] = {c->d_window, c->d_tw, c->d_tw_exact, c->d_claim, c->d_lut, c->d_fast, c->d_in, c->d_out, c->d_aux, c->d_fb_bin, c->d_fb_w, c->d_fb_packed};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
   if (c->ev_start) (void)hipEventDestroy(c->ev_start);
@@ -357,6 +359,30 @@ int sono_set_tables(sono_ctx* c, const float* window, const double* tw_cos, cons
   return rc != SONO_OK ? rc : refresh_routes(c);
 }
 
+// out[y] = m[o] * w0[y] + m[o + 1] * w1[y], a tap outside [0, half) contributing nothing, as two taps that are always
+// readable when m[half] is a zero: {tap, w0, w1} with o = -1 turned into {0, w1, 0}, o = half - 1 into {o, w0, 0} (its
+// second tap reads the zero), anything further out into {0, 0, 0}.
+static void pack_filterbank(const int32_t* bin, const double* w0, const double* w1, uint32_t half, std::vector<uint32_t>& packed) {
+  packed.assign((size_t)3 * half, 0u);
+  for (uint32_t y = 0; y < half; y++) {
+    const int64_t o = bin[y];
+    const bool v0 = o >= 0 && o < (int64_t)half, v1 = o + 1 >= 0 && o + 1 < (int64_t)half;
+    int32_t t = 0;
+    float a = 0.0f, b = 0.0f;
+    if (v0) {
+      t = (int32_t)o;
+      a = (float)w0[y];
+      if (v1) b = (float)w1[y];
+    } else if (v1) {
+      t = (int32_t)(o + 1);
+      a = (float)w1[y];
+    }
+    std::memcpy(&packed[y], &t, 4);
+    std::memcpy(&packed[half + y], &a, 4);
+    std::memcpy(&packed[2 * half + y], &b, 4);
+  }
+}
+
 int sono_set_filterbank(sono_ctx* c, const int32_t* bin, const double* w0, const double* w1) {
   if (!c) return SONO_ERR_ARG;
   HIP_TRY(c, hipSetDevice(c->device));
@@ -364,8 +390,10 @@ int sono_set_filterbank(sono_ctx* c, const int32_t* bin, const double* w0, const
   if (!bin) {
     if (c->d_fb_bin) HIP_TRY(c, hipFree(c->d_fb_bin));
     if (c->d_fb_w) HIP_TRY(c, hipFree(c->d_fb_w));
+    if (c->d_fb_packed) HIP_TRY(c, hipFree(c->d_fb_packed));
     c->d_fb_bin = nullptr;
     c->d_fb_w = nullptr;
+    c->d_fb_packed = nullptr;
     return refresh_routes(c);
   }
   if (!w0 || !w1) return fail(c, SONO_ERR_ARG, "filter bank weights missing");
@@ -376,6 +404,12 @@ int sono_set_filterbank(sono_ctx* c, const int32_t* bin, const double* w0, const
   HIP_TRY(c, hipMemcpy(c->d_fb_bin, bin, sizeof(int32_t) * half, hipMemcpyHostToDevice));
   HIP_TRY(c, hipMemcpy(c->d_fb_w, w0, sizeof(double) * half, hipMemcpyHostToDevice));
   HIP_TRY(c, hipMemcpy(c->d_fb_w + half, w1, sizeof(double) * half, hipMemcpyHostToDevice));
+  {
+    std::vector<uint32_t> packed;
+    pack_filterbank(bin, w0, w1, half, packed);
+    if (!c->d_fb_packed) HIP_TRY(c, hipMalloc(&c->d_fb_packed, packed.size() * 4));
+    HIP_TRY(c, hipMemcpy(c->d_fb_packed, packed.data(), packed.size() * 4, hipMemcpyHostToDevice));
+  }
   return refresh_routes(c);
 }
 
@@ -490,14 +524,25 @@ struct IndexScratch {
 };
 
 // One frame range through the kernels.  Allocates nothing and does not wait.
-static int launch_range(sono_ctx* c, const StftParams& q, const IndexScratch& aux, bool fused_ok) {
-  if ((q.frame0 + q.nframes - 1) * q.hop + q.n > q.n_samples) return fail(c, SONO_ERR_ARG, "frame range exceeds the signal");
+static int launch_range(sono_ctx* c, const StftParams& q_in, const IndexScratch& aux, bool fused_ok) {
+  if ((q_in.frame0 + q_in.nframes - 1) * q_in.hop + q_in.n > q_in.n_samples) return fail(c, SONO_ERR_ARG, "frame range exceeds the signal");
   int r = 1;
+  const bool exact = c->cfg.arith == SONO_ARITH_EXACT_F64;
+  const bool rgba = q_in.out_kind == SONO_OUT_RGBA8;
+  // A non-linear frequency scale at 1024 points: the float32 index kernel applies the two taps per output bin itself
+  // (whole groups of four bins, as for the linear scale; the image goes through a chunk of indices, whose band is
+  // rounded outwards).  Other sizes, ragged index bands and tables whose pairs would leak take the route through a
+  // plane of magnitudes further down.
+  const bool fb_fused = q_in.fb_bin && !exact && c->fb_fast_mode && c->d_fb_packed && q_in.n == 1024 && c->pair_idx_ok &&
+                        (rgba || (q_in.out_kind == SONO_OUT_U8_INDEX && !((q_in.bin_lo | q_in.bin_hi | q_in.out_bins | q_in.out_bin0) & 3u)));
+  StftParams q = q_in;
+  if (fb_fused) {
+    q.fast_mode = c->fb_fast_mode;
+    q.fb_packed = c->d_fb_packed;
+  }
   StftParams qq = q;
   if (!qq.lut) qq.lut = c->d_lut + 256;
-  const bool fast = c->fast_mode != 0;
-  const bool exact = c->cfg.arith == SONO_ARITH_EXACT_F64;
-  const bool rgba = q.out_kind == SONO_OUT_RGBA8;
+  const bool fast = c->fast_mode != 0 || fb_fused;
   if (fused_ok && fast && rgba && (fast_rgba_available(qq) || fast512_rgba_available(qq) || fast2048_rgba_available(qq) || fast4096_rgba_available(qq))) {
     // the fast kernel writes the image itself; its rounds go through a scratch buffer sized at set-up
     if (!c->d_aux || c->d_aux_bytes < fast_rgba_scratch_bytes())
@@ -565,7 +610,7 @@ static int launch_range(sono_ctx* c, const StftParams& q, const IndexScratch& au
   // Non-linear frequency scales in the float32 arithmetic: the float32 transform kernel writes a chunk of magnitudes
   // ([frame][n/2] float32, in the context's scratch), the filter-bank kernel gathers its two taps per output bin from it
   // and quantises; for the image a chunk of indices and the colour-map kernel follow.
-  if (q.fb_bin && !exact && (c->fb_fast_mode || c->fb_mw_ok) && aux.ptr &&
+  if (q.fb_bin && !fb_fused && !exact && (c->fb_fast_mode || c->fb_mw_ok) && aux.ptr &&
       (q.out_kind == SONO_OUT_U8_INDEX || (rgba && q.row_of_bin0 == (int32_t)q.bin_hi - 1))) {
     const uint32_t half = q.n / 2;
     const uint32_t lo4 = q.bin_lo & ~3u, hi4 = (q.bin_hi + 3u) & ~3u, nb4 = hi4 - lo4;

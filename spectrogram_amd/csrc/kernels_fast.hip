@@ -61,12 +61,15 @@ constexpr int lds_bytes(int waves) { return kTwBytes + kWinBytes + waves * 2 * k
 // second pass reads factor 32*(g mod t) + lane of stage T = 32t from a [31][32] copy in LDS, and there
 // is no twiddle multiplication between the passes (it is part of those factors).
 // kOutDb / kOutMag: float32 20*log10(m) / m per bin, [frame][bin] (what the tolerance tests read).
-constexpr int kOutU8 = 0, kOutFeatures = 2, kOutDb = 3, kOutMag = 4;
+// kOutU8Bank: colour indices on a non-linear frequency scale: out[y] = m[tap[y]] * w0[y] + m[tap[y] + 1] * w1[y] over the
+// frame's magnitudes (spectrogram.esm.js:479-488 with the two non-zero weights of a row), then the quantiser.
+constexpr int kOutU8 = 0, kOutFeatures = 2, kOutDb = 3, kOutMag = 4, kOutU8Bank = 5;
 template <bool PLUGIN, typename In, int HOP32, int OUT, bool TABLE>
 __global__ __launch_bounds__(kMaxWaves * 64, 4) void stft1024_u8_kernel(StftParams p, FastScale fs,
                                                                         const float2* __restrict__ tw_table) {
   constexpr bool FEAT = OUT == kOutFeatures, FLT = OUT == kOutDb || OUT == kOutMag;
-  constexpr bool SINGLE = HOP32 < 0;
+  constexpr bool SINGLE = HOP32 < 0, BANK = OUT == kOutU8Bank;
+  static_assert(!(SINGLE && BANK), "the filter bank comes with the paired flavour");
   static_assert(!(SINGLE && FEAT), "the feature records come from the paired flavour (its marks cover the cross-talk)");
   constexpr int kThreads = kMaxWaves * 64, kWaves = kMaxWaves;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -248,6 +251,7 @@ __global__ __launch_bounds__(kMaxWaves * 64, 4) void stft1024_u8_kernel(StftPara
     // rounding noise and the pair's cross-talk scale with; see feature_uncertain)
     const bool banded = p.bin_lo != 0 || p.bin_hi != kNPoints / 2;  // wave-uniform
     float seen_a = 0.0f, seen_b = 0.0f;
+    float mg_a[BANK ? 16 : 1], mg_b[BANK ? 16 : 1];  // BANK: this lane's magnitudes of both frames, [8P + 4g + B]
     int lq = l;
     // (FEAT: an opaque copy keeps the loop-invariant bin numbers and band tests out of registers the transform needs;
     // hoisted, they were spilled and every reload waited on the memory counter)
@@ -285,6 +289,9 @@ __global__ __launch_bounds__(kMaxWaves * 64, 4) void stft1024_u8_kernel(StftPara
     if constexpr (FEAT) {                                                    \
       fa[B] = ma;                                                            \
       fb[B] = mb;                                                            \
+    } else if constexpr (BANK) {                                             \
+      mg_a[8 * P + 4 * g + B] = __builtin_amdgcn_sqrtf(ma); /* (1 ulp: an index step is 0.3 dB) */ \
+      mg_b[8 * P + 4 * g + B] = __builtin_amdgcn_sqrtf(mb);                  \
     } else if constexpr (FLT) {                                              \
       fa[B] = OUT == kOutDb ? fast_db(ma, fs) : __builtin_sqrtf(ma) * mag_scale; \
       fb[B] = OUT == kOutDb ? fast_db(mb, fs) : __builtin_sqrtf(mb) * mag_scale; \
@@ -320,13 +327,73 @@ __global__ __launch_bounds__(kMaxWaves * 64, 4) void stft1024_u8_kernel(StftPara
             if (st_a) *reinterpret_cast<float4*>(o + row_a) = make_float4(fa[0], fa[1], fa[2], fa[3]);
             if (st_b) *reinterpret_cast<float4*>(o + row_b) = make_float4(fb[0], fb[1], fb[2], fb[3]);
           }
-        } else if (!FEAT && in_band) {
+        } else if (!FEAT && !BANK && in_band) {
           const uint32_t col = k - p.out_bin0;
           if (st_a) *reinterpret_cast<uint32_t*>(out + row_a + col) = wa;
           if (st_b) *reinterpret_cast<uint32_t*>(out + row_b + col) = wb;
         }
       }
       wave_sync();  // the buffer is rewritten by the next half / the next iteration's transpose
+    }
+    if constexpr (BANK) {
+      // Both frames' magnitudes go to this half-wavefront's buffer (free between the epilogue and the next transpose),
+      // each followed by a zero that a tap at the last bin reads as its neighbour; then every lane gathers the two taps
+      // of its 16 output bins per frame.  The tap tables are read from memory (L1-resident, 6 KiB) every iteration.
+      float* ma_lds = reinterpret_cast<float*>(fbuf);
+      float* mb_lds = ma_lds + 516;
+      static_assert((516 + 513) * 4 <= kFftBufBytes, "two frames of magnitudes must fit the transpose buffer");
+      uint32_t top_a = 0, top_b = 0;  // largest bit pattern: magnitudes are >= +0, so infinities and NaNs sort highest
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int at = 256 * (j >> 1) + 4 * (l + 32 * (j & 1));
+        *reinterpret_cast<float4*>(ma_lds + at) = make_float4(mg_a[4 * j], mg_a[4 * j + 1], mg_a[4 * j + 2], mg_a[4 * j + 3]);
+        *reinterpret_cast<float4*>(mb_lds + at) = make_float4(mg_b[4 * j], mg_b[4 * j + 1], mg_b[4 * j + 2], mg_b[4 * j + 3]);
+#pragma unroll
+        for (int B = 0; B < 4; ++B) {
+          top_a = max(top_a, __float_as_uint(mg_a[4 * j + B]));  // (a NaN with its sign bit set sorts higher still)
+          top_b = max(top_b, __float_as_uint(mg_b[4 * j + B]));
+        }
+      }
+      if (l == 0) ma_lds[512] = mb_lds[512] = 0.0f;
+      wave_sync();
+      // one infinite or NaN magnitude turns every output bin of its frame NaN: the reference's row sum visits every
+      // bin of the spectrum, and 0 * inf and 0 * NaN are NaN (spectrogram.esm.js:479-488)
+      const uint64_t ball_a = __ballot(top_a >= 0x7f800000u), ball_b = __ballot(top_b >= 0x7f800000u);
+      const uint32_t keep_a = (uint32_t)(h ? ball_a >> 32 : ball_a) ? 0u : ~0u;  // (NaN quantises to index 0)
+      const uint32_t keep_b = (uint32_t)(h ? ball_b >> 32 : ball_b) ? 0u : ~0u;
+      int lf = l;
+      asm volatile("" : "+v"(lf));  // (the table reads stay inside the loop: hoisted they would hold 48 registers)
+      const char* bank = reinterpret_cast<const char*>(p.fb_packed) + 2048;  // tap at -2048, w0 at 0, w1 at +2048
+      // the quantiser on a magnitude instead of its square: log2(v^2) = 2 log2(v); a negative sum (negative weights)
+      // has no logarithm and quantises to index 0 like the reference's NaN
+      FastScale fm = fs;
+      fm.a = 2.0f * fs.a;
+#pragma unroll 1
+      for (int g = 0; g < 4; ++g) {
+        const int quad = lf + 32 * g, y0 = 4 * quad;
+        const char* at = bank + 16 * quad;
+        const int4 tp = *reinterpret_cast<const int4*>(at - 2048);
+        const float4 u0 = *reinterpret_cast<const float4*>(at), u1 = *reinterpret_cast<const float4*>(at + 2048);
+        const int taps[4] = {tp.x, tp.y, tp.z, tp.w};
+        const float c0[4] = {u0.x, u0.y, u0.z, u0.w}, c1[4] = {u1.x, u1.y, u1.z, u1.w};
+        uint32_t wa = 0, wb = 0;
+#pragma unroll
+        for (int B = 0; B < 4; ++B) {
+          const float* ta = ma_lds + taps[B];
+          const float va = __builtin_fmaf(ta[1], c1[B], ta[0] * c0[B]);
+          const float vb = __builtin_fmaf(ta[517], c1[B], ta[516] * c0[B]);
+          if (B == 0) { wa = fast_plugin_byte<0>(va, fm, wa); wb = fast_plugin_byte<0>(vb, fm, wb); }
+          if (B == 1) { wa = fast_plugin_byte<1>(va, fm, wa); wb = fast_plugin_byte<1>(vb, fm, wb); }
+          if (B == 2) { wa = fast_plugin_byte<2>(va, fm, wa); wb = fast_plugin_byte<2>(vb, fm, wb); }
+          if (B == 3) { wa = fast_plugin_byte<3>(va, fm, wa); wb = fast_plugin_byte<3>(vb, fm, wb); }
+        }
+        if (y0 >= (int)p.bin_lo && y0 < (int)p.bin_hi) {
+          const uint32_t col = y0 - p.out_bin0;
+          if (st_a) *reinterpret_cast<uint32_t*>(out + row_a + col) = wa & keep_a;
+          if (st_b) *reinterpret_cast<uint32_t*>(out + row_b + col) = wb & keep_b;
+        }
+      }
+      wave_sync();  // the buffer is rewritten by the next iteration's transpose
     }
     if constexpr (FEAT) {
       // reduce over the 32 lanes of the half-wavefront: larger |X|^2 wins, equal values go to the lower bin
@@ -413,7 +480,7 @@ bool fast_features_available(const StftParams& p) {
 // The fused image output needs the flipped full-height row mapping (any band: rows outside it are masked) and store
 // offsets (a few image rows) that fit 32 bits.
 bool fast_rgba_available(const StftParams& p) {
-  if (!fast_base_available(p) || !p.pair_idx_ok) return false;
+  if (!fast_base_available(p) || !p.pair_idx_ok || p.fb_packed) return false;
   if (p.bin_lo >= p.bin_hi) return false;
   if (p.row_of_bin0 != (int32_t)p.bin_hi - 1) return false;
   if (p.width == 0 || p.width > ((uint64_t)1 << 24) || !p.lut) return false;
@@ -431,6 +498,9 @@ int launch_stft_fast(const StftParams& p, void* stream_v) {
   // one frame per transform where two would not do: colour indices under a table whose cross-talk could show
   // (StftParams::pair_idx_ok), float32 outputs under any asymmetric table (StftParams::pair_exact)
   const bool single = p.fast_mode == 2 && ((p.out_kind == SONO_OUT_U8_INDEX && !p.pair_idx_ok) || (flt && !p.pair_exact));
+  // a non-linear frequency scale: colour indices only, plugin quantiser, paired frames
+  const bool bank = p.fb_packed != nullptr;
+  if (bank && (p.out_kind != SONO_OUT_U8_INDEX || single || p.scale_mode != SONO_SCALE_PLUGIN_DB)) return 1;
   if (rgba) {
     if (!fast_rgba_available(p)) return 1;
     return launch_stft_fast_rgba(p, stream_v);  // the image writer is a kernel of its own (kernels_fast_rgba.hip)
@@ -473,6 +543,7 @@ int launch_stft_fast(const StftParams& p, void* stream_v) {
     if (feat) SONO_LAUNCH_O(PLUGIN, In, H, kOutFeatures);                                              \
     else if (p.out_kind == SONO_OUT_F32_DB) SONO_LAUNCH_O(PLUGIN, In, H, kOutDb);                           \
     else if (p.out_kind == SONO_OUT_F32_MAG) SONO_LAUNCH_O(PLUGIN, In, H, kOutMag);                         \
+    else if (bank) SONO_LAUNCH_O(true, In, H, kOutU8Bank);                                                  \
     else SONO_LAUNCH_O(PLUGIN, In, H, kOutU8);                                                              \
   } while (0)
 #define SONO_LAUNCH(PLUGIN, In)                                                                             \
@@ -495,7 +566,10 @@ int launch_stft_fast(const StftParams& p, void* stream_v) {
 #undef SONO_LAUNCH_H
 #undef SONO_LAUNCH_O
 #undef SONO_LAUNCH_T
-  note_kernel(single ? "stft1024_u8_kernel<table,single>" : tab ? "stft1024_u8_kernel<table>" : "stft1024_u8_kernel<roots>");
+  note_kernel(single ? "stft1024_u8_kernel<table,single>"
+              : bank ? (tab ? "stft1024_u8_kernel<table,bank>" : "stft1024_u8_kernel<roots,bank>")
+              : tab  ? "stft1024_u8_kernel<table>"
+                     : "stft1024_u8_kernel<roots>");
   return hipGetLastError() == hipSuccess ? SONO_OK : SONO_ERR_DEVICE;
 }
 

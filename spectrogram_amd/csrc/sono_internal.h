@@ -49,6 +49,7 @@ struct StftParams {
   const int32_t* fb_bin;  // device: non-linear frequency scale, first tap of output bin i (n/2 entries), or nullptr = linear
   const double* fb_w0;    // device: weight of bin fb_bin[i]
   const double* fb_w1;    // device: weight of bin fb_bin[i] + 1
+  const void* fb_packed;  // device, set only for the 1024-point float32 index kernel: int32 tap[n/2], float w0[n/2], float w1[n/2]
   void* tile_scratch;     // device: fast_rgba_scratch_bytes() of scratch for the 2048/4096-point image writers, or nullptr
   uint32_t scale_mode, out_kind, in_kind;
   uint32_t feat_lo, feat_hi;  // SONO_OUT_FEATURES from a float32 kernel: the band the records are for.  The kernels search whole

@@ -683,7 +683,8 @@ def test_plugin_scaled_get_frequencies(case):
 @pytest.mark.parametrize("n,hop", [(1024, 256), (512, 128), (2048, 512), (4096, 1024)])
 @pytest.mark.parametrize("scale", ["mel", "logarithmic"])
 def test_scaled_frequencies_stay_on_the_float32_kernels(n, hop, scale):
-    """A non-linear frequency scale in the float32 arithmetic: magnitudes from the fast transform kernels, then the
+    """A non-linear frequency scale in the float32 arithmetic.  1024 points: the index kernel gathers the two taps of
+    every output bin itself.  Other sizes: magnitudes from the fast transform kernels, then the
     filter-bank kernel; the general kernel is not involved -- except at 4096 points, where the only fast kernel with a
     magnitude output transforms two frames at once and the recurrence factors would let a full-scale frame leave a
     trace above the display floor in its partner.  Indices within 1 LSB of the checker's, the image is the
@@ -701,7 +702,10 @@ def test_scaled_frequencies_stay_on_the_float32_kernels(n, hop, scale):
         eng.set_filterbank(*fb)
         got = eng.stft(x)
         route = eng.kernel_route()
-    assert ("general" not in route or n == 4096) and "filterbank_index_kernel" in route, route
+    if n == 1024:
+        assert route == "stft1024_u8_kernel<table,bank>", route
+    else:
+        assert ("general" not in route or n == 4096) and "filterbank_index_kernel" in route, route
     d = cyc_diff(got, ref)
     assert got.shape == ref.shape and d.max() <= 1 and (d != 0).mean() < 0.02, (d.max(), (d != 0).mean())
     lut = (np.arange(1024, dtype=np.uint32) * 5 % 256).astype(np.uint8)
@@ -712,7 +716,15 @@ def test_scaled_frequencies_stay_on_the_float32_kernels(n, hop, scale):
         img = eng.stft(x)
         route = eng.kernel_route()
     assert ("general" not in route or n == 4096) and "colorize_kernel" in route, route
+    assert n != 1024 or route == "stft1024_u8_kernel<table,bank>:u8 + colorize_kernel", route
     assert np.array_equal(img, lut.reshape(256, 4)[got[:, lo:hi].T[::-1]])
+    # an index band that does not start and end on a group of four bins: through the magnitude plane at every size
+    with plugin_engine(n, hop, F.ARITH_FAST_F32, bin_lo=lo, bin_hi=hi) as eng:
+        eng.set_filterbank(*fb)
+        band = eng.stft(x)
+        assert "filterbank_index_kernel" in eng.kernel_route()
+    db = cyc_diff(band, got[:, lo:hi])     # (1024 points: two float32 routes, which may round a borderline bin differently)
+    assert db.max() <= (1 if n == 1024 else 0) and (db != 0).mean() < 0.01
     xn = x.copy()
     xn[n + 5 * hop + 17] = np.nan
     with plugin_engine(n, hop, F.ARITH_FAST_F32) as eng:
@@ -722,6 +734,12 @@ def test_scaled_frequencies_stay_on_the_float32_kernels(n, hop, scale):
     hit = np.array([f * hop <= s0 < f * hop + n for f in range(len(gn))])
     assert hit.sum() == n // hop and (gn[hit] == 0).all()
     assert np.array_equal(gn[~hit], got[~hit])
+    # a sample large enough to push one frame's magnitudes to infinity does the same (0 * inf is NaN in the row sum)
+    xn[s0] = 3e38
+    with plugin_engine(n, hop, F.ARITH_FAST_F32) as eng:
+        eng.set_filterbank(*fb)
+        gi = eng.stft(xn)
+    assert np.array_equal(gi, gn)
 
 
 # ------------------------------------------------------------------ the canvas step of drawSpectrogram (:357-381)
