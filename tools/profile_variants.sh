@@ -29,5 +29,9 @@ run plugin_rgba_2048 600 5 rgba 2048 512 plugin
 run plugin_u8_1024_exact 120 3 u8 1024 256 plugin 0 0 exact
 run plugin_u8_1024_mel 600 5 u8 1024 256 plugin 0 0 fast mel
 run worker_rgba_1024_exact 120 3 rgba 1024 256 worker 0 0 exact
+run plugin_rgba_1024_mel 600 5 rgba 1024 256 plugin 0 0 fast mel
+export SONO_BENCH_WINDOW=8   # rectangular window: one frame per transform under the plugin's table
+run plugin_u8_1024_rectangular 600 5 u8 1024 256 plugin
+unset SONO_BENCH_WINDOW
 rm -f "$OUT"/*.log
 ls "$OUT"
