@@ -441,6 +441,44 @@ def test_one_frame_per_transform_where_pairing_would_leak():
     assert np.abs(db - want)[near].max() <= 0.01
 
 
+@pytest.mark.parametrize("flavour", ["single", "bank"])
+@pytest.mark.parametrize("hop,frames", [(256, 16), (256, 17), (512, 33), (100, 130), (333, 67), (768, 35)])
+@pytest.mark.parametrize("i16", [False, True])
+def test_one_frame_and_filter_bank_flavours_over_hops_inputs_and_lengths(flavour, hop, frames, i16):
+    """The 1024-point index kernel's one-frame-per-transform flavour (rectangular window under the plugin's table)
+    and its filter-bank flavour (mel): hops with and without the shared sample run (multiples of 32 or not), float32
+    and int16 samples, frame counts from the smallest the kernel takes (16) over odd counts to a few rounds of the
+    grid; a band of whole groups of four bins.  Within 1 LSB of the checker."""
+    n, sr = 1024, 250000
+    rng = np.random.default_rng(hop * 7 + frames)
+    L = n + hop * (frames - 1) + int(rng.integers(0, hop))
+    t = np.arange(L, dtype=np.float64)
+    x = (rng.standard_normal(L) * 0.02 + 0.5 * np.sin(t * (0.3 + 0.4 * t / L))).astype(np.float32)
+    if i16:
+        q = np.round(x * 32767).astype(np.int16)
+        x_in, x = q, q.astype(np.float32) / np.float32(32768.0)
+    else:
+        x_in = x
+    lo, hi = 8, 452
+    kw = dict(in_kind=F.IN_I16 if i16 else F.IN_F32, bin_lo=lo, bin_hi=hi)
+    if flavour == "single":
+        ref = oracle.plugin_get_frequencies(x, n, n - hop, window="rectangular")
+        route = "stft1024_u8_kernel<table,single>"
+        with plugin_engine(n, hop, F.ARITH_FAST_F32, window="rectangular", **kw) as eng:
+            got = eng.stft(x_in)
+            assert eng.kernel_route() == route
+    else:
+        ref = oracle.plugin_get_frequencies_scaled(x, n, n - hop, "mel", sr)
+        route = "stft1024_u8_kernel<table,bank>"
+        with plugin_engine(n, hop, F.ARITH_FAST_F32, **kw) as eng:
+            eng.set_filterbank(*E.filterbank_table("mel", n, sr))
+            got = eng.stft(x_in)
+            assert eng.kernel_route() == route
+    assert got.shape == (frames, hi - lo)
+    d = cyc_diff(got, ref[:frames, lo:hi])
+    assert d.max() <= 1 and (d != 0).mean() < 0.02
+
+
 # ------------------------------------------------------------------ per-frame features (SONO_OUT_FEATURES)
 def test_features_exact_bit_exact_against_checker():
     """Integer feature indices are bit-exact: peak_bin is the strict-> first-wins argmax of the float32
