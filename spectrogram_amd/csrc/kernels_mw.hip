@@ -94,6 +94,9 @@ __device__ __forceinline__ void group_sync() {
 
 // M > 0: hop == M * N/16, so frame B's sample t + (N/16)*a' is frame A's sample t + (N/16)*(a' + M) and one
 // run of 16 + M loads feeds both frames (75 %, 87.5 % and 93.75 % overlap are M = 4, 2, 1).  M == 0: any hop.
+// M < 0: ONE real frame per transform (imaginary part zero; its spectrum is Z itself, i.e. the reference's own
+// transform of the frame), for twiddle tables under which a frame would leave a visible trace in a partner
+// (StftParams::pair_idx_ok) or float32 outputs would carry it (pair_exact).
 // OUT: kOutU8 [frame][bin] colour indices; kOutDb / kOutMag [frame][bin] float32 20*log10(m) / m; kOutFeatures
 // [frame] spectral peak (strict-> first-wins argmax of |X|^2 over the band and that bin's colour index).
 constexpr int kOutU8 = 0, kOutFeatures = 2, kOutDb = 3, kOutMag = 4;
@@ -101,6 +104,8 @@ template <int LOG2N, int G, int M, bool PLUGIN, typename In, int OUT>
 __global__ __launch_bounds__((1 << LOG2N) / 16 * G, 4) void stft_mw_kernel(StftParams p, FastScale fs) {
   constexpr int N = 1 << LOG2N, TN = N / 16, CB = LOG2N - 8, NC = 1 << CB, SETS = 16 / NC;
   constexpr bool FEAT = OUT == kOutFeatures, FLT = OUT == kOutDb || OUT == kOutMag;
+  constexpr bool SINGLE = M < 0;
+  static_assert(!(SINGLE && FEAT), "the feature records come from the paired flavour (its marks cover the cross-talk)");
   constexpr int kWavesPerGroup = TN > 64 ? TN / 64 : 1;
   __shared__ float s_best[FEAT ? G * kWavesPerGroup * 2 : 1];   // FEAT, transforms wider than a wavefront:
   __shared__ int s_bestk[FEAT ? G * kWavesPerGroup * 2 : 1];    // per-wavefront peaks of the two frames
@@ -128,21 +133,27 @@ __global__ __launch_bounds__((1 << LOG2N) / 16 * G, 4) void stft_mw_kernel(StftP
 #pragma unroll
   for (int a1 = 0; a1 < 16; ++a1) win[rev4(a1)] = p.window[t + TN * a1];
 
-  const uint64_t npairs = (p.nframes + 1) >> 1;
+  const uint64_t npairs = SINGLE ? p.nframes : (p.nframes + 1) >> 1;  // transforms
   for (uint64_t base = (uint64_t)blockIdx.x * G; base < npairs; base += (uint64_t)gridDim.x * G) {
     // every group of the workgroup goes through every iteration (the larger sizes meet at barriers); one
     // without a pair of its own repeats the last pair and stores nothing
     const bool active = base + grp < npairs;
     const uint64_t pair = active ? base + grp : npairs - 1;
-    uint64_t f0 = 2 * pair;
+    uint64_t f0 = SINGLE ? pair : 2 * pair;
     bool st_a = active;
-    if (f0 + 1 >= p.nframes) {  // odd last frame: computed as the second member of the pair before it
+    if (!SINGLE && f0 + 1 >= p.nframes) {  // odd last frame: computed as the second member of the pair before it
       f0 -= 1;
       st_a = false;
     }
     const In* xa = x + (p.frame0 + f0) * p.hop + t;
     float re[16], im[16];
-    if constexpr (M > 0) {
+    if constexpr (SINGLE) {
+#pragma unroll
+      for (int a1 = 0; a1 < 16; ++a1) {
+        re[rev4(a1)] = ld<In>(xa, (uint64_t)TN * a1);
+        im[rev4(a1)] = 0.0f;
+      }
+    } else if constexpr (M > 0) {
       float raw[16 + M];
 #pragma unroll
       for (int a1 = 0; a1 < 16 + M; ++a1) raw[a1] = ld<In>(xa, (uint64_t)TN * a1);
@@ -214,7 +225,8 @@ __global__ __launch_bounds__((1 << LOG2N) / 16 * G, 4) void stft_mw_kernel(StftP
     group_sync<TN>();
     // epilogue: thread handles the bin quads q = t, t + TN (N/8 quads per frame)
     const uint64_t row_a = (p.col0 + f0) * p.out_bins, row_b = row_a + p.out_bins;
-    const float mag_scale = PLUGIN ? 1.0f / (float)N : 0.5f;  // the pair separation leaves 2*X; plugin: 2/N * |X|
+    // the pair separation leaves 2*X; plugin: 2/N * |X|
+    const float mag_scale = SINGLE ? (PLUGIN ? 2.0f / (float)N : 1.0f) : PLUGIN ? 1.0f / (float)N : 0.5f;
     float best_a = -1.0f, best_b = -1.0f;                     // FEAT: this thread's largest |X|^2 so far and its bin
     int kbest_a = (int)p.bin_lo, kbest_b = (int)p.bin_lo;
     float next_a = -1.0f, next_b = -1.0f;                     // FEAT: the runner-up (decides whether float32 can tell)
@@ -229,7 +241,7 @@ __global__ __launch_bounds__((1 << LOG2N) / 16 * G, 4) void stft_mw_kernel(StftP
   {                                                                            \
     const int km = (N - k - B) & (N - 1);                                      \
     const float zr = s_re[cellZ + B], zi = s_im[cellZ + B];                    \
-    const float pr = s_re[pad(km)], pi = s_im[pad(km)];                        \
+    const float pr = SINGLE ? 0.0f : s_re[pad(km)], pi = SINGLE ? 0.0f : s_im[pad(km)]; \
     const float ar = zr + pr, ai = zi - pi;                                    \
     const float br = zi + pi, bi = pr - zr;                                    \
     const float ma = __builtin_fmaf(ar, ar, ai * ai);                          \
@@ -253,10 +265,10 @@ __global__ __launch_bounds__((1 << LOG2N) / 16 * G, 4) void stft_mw_kernel(StftP
         if constexpr (FLT) {
           float* o = reinterpret_cast<float*>(p.out) + col;
           if (st_a) *reinterpret_cast<float4*>(o + row_a) = make_float4(fa[0], fa[1], fa[2], fa[3]);
-          if (active) *reinterpret_cast<float4*>(o + row_b) = make_float4(fb[0], fb[1], fb[2], fb[3]);
+          if (!SINGLE && active) *reinterpret_cast<float4*>(o + row_b) = make_float4(fb[0], fb[1], fb[2], fb[3]);
         } else if constexpr (!FEAT) {
           if (st_a) *reinterpret_cast<uint32_t*>(out + row_a + col) = wa;
-          if (active) *reinterpret_cast<uint32_t*>(out + row_b + col) = wb;
+          if (!SINGLE && active) *reinterpret_cast<uint32_t*>(out + row_b + col) = wb;
         }
       }
     }
@@ -322,7 +334,7 @@ __global__ __launch_bounds__((1 << LOG2N) / 16 * G, 4) void stft_mw_kernel(StftP
 }  // namespace mw
 
 bool mw_u8_available(const StftParams& p) {
-  if ((p.n != 512 && p.n != 2048 && p.n != 4096) || !p.mw_ok || !p.twiddles || !p.pair_idx_ok) return false;
+  if ((p.n != 512 && p.n != 2048 && p.n != 4096) || !p.mw_ok || !p.twiddles) return false;  // (pairs that would leak: one frame per transform)
   if ((p.bin_lo & 3) || (p.bin_hi & 3) || (p.out_bins & 3) || (p.out_bin0 & 3)) return false;
   if (p.nframes < 2) return false;
   return true;
@@ -333,8 +345,9 @@ int launch_stft_mw(const StftParams& p, void* stream_v) {
   const bool u8 = p.out_kind == SONO_OUT_U8_INDEX, feat = p.out_kind == SONO_OUT_FEATURES;
   const bool flt = p.out_kind == SONO_OUT_F32_DB || p.out_kind == SONO_OUT_F32_MAG;
   if (!(u8 || feat || flt)) return 1;
-  if (flt && !p.pair_exact) return 1;  // two frames per transform: see StftParams::pair_exact
-  if (u8 && !p.pair_idx_ok) return 1;  // ... and StftParams::pair_idx_ok
+  // one frame per transform where two would not do: float32 outputs under an asymmetric table (StftParams::pair_exact),
+  // colour indices under a table whose cross-talk could show (StftParams::pair_idx_ok)
+  const bool single = (flt && !p.pair_exact) || (u8 && !p.pair_idx_ok);
   if (feat) {  // features do not use the output row layout
     if ((p.n != 512 && p.n != 2048 && p.n != 4096) || !p.mw_ok || !p.twiddles || (p.bin_lo & 3) || (p.bin_hi & 3) ||
         p.bin_lo >= p.bin_hi || p.nframes < 2)
@@ -345,10 +358,12 @@ int launch_stft_mw(const StftParams& p, void* stream_v) {
   if (reinterpret_cast<uintptr_t>(p.out) & (flt ? 15 : 3)) return 1;
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_v);
   FastScale fs = make_fast_scale(p.scale_mode, p.n, p.gain_db, p.range_db);
-  fs.b -= 2.0f * fs.a;  // the pair separation leaves 2*X
+  if (!single) {
+    fs.b -= 2.0f * fs.a;  // the pair separation leaves 2*X
+    fs.db_off -= 2.0f * 3.0102999566f;
+  }
   fs.xtalk = (float)p.pair_asym;
-  fs.db_off -= 2.0f * 3.0102999566f;
-  const uint64_t npairs = (p.nframes + 1) / 2;
+  const uint64_t npairs = single ? p.nframes : (p.nframes + 1) / 2;  // transforms
   const int cus = device_cu_count();
   const int groups = p.n == 512 ? 8 : 1;  // transforms per workgroup
   const uint64_t need = (npairs + groups - 1) / groups;
@@ -363,6 +378,9 @@ int launch_stft_mw(const StftParams& p, void* stream_v) {
 #define SONO_MW_M(L2, GR, PL, In)                                                                          \
   do {                                                                                                     \
     if (feat) SONO_MW(L2, GR, 0, PL, In, kOutFeatures);                                                    \
+    else if (single && p.out_kind == SONO_OUT_F32_DB) SONO_MW(L2, GR, -1, PL, In, kOutDb);                 \
+    else if (single && p.out_kind == SONO_OUT_F32_MAG) SONO_MW(L2, GR, -1, PL, In, kOutMag);               \
+    else if (single) SONO_MW(L2, GR, -1, PL, In, kOutU8);                                                  \
     else if (p.out_kind == SONO_OUT_F32_DB) SONO_MW(L2, GR, 0, PL, In, kOutDb);                            \
     else if (p.out_kind == SONO_OUT_F32_MAG) SONO_MW(L2, GR, 0, PL, In, kOutMag);                          \
     else if (m == 1) SONO_MW(L2, GR, 1, PL, In, kOutU8); else if (m == 2) SONO_MW(L2, GR, 2, PL, In, kOutU8); \
@@ -382,7 +400,8 @@ int launch_stft_mw(const StftParams& p, void* stream_v) {
 #undef SONO_MW_IN
 #undef SONO_MW_M
 #undef SONO_MW
-  note_kernel(p.n == 4096 ? "stft_mw_kernel<4096>" : p.n == 2048 ? "stft_mw_kernel<2048>" : "stft_mw_kernel<512>");
+  note_kernel(single ? (p.n == 4096 ? "stft_mw_kernel<4096,single>" : p.n == 2048 ? "stft_mw_kernel<2048,single>" : "stft_mw_kernel<512,single>")
+                     : (p.n == 4096 ? "stft_mw_kernel<4096>" : p.n == 2048 ? "stft_mw_kernel<2048>" : "stft_mw_kernel<512>"));
   return hipGetLastError() == hipSuccess ? SONO_OK : SONO_ERR_DEVICE;
 }
 

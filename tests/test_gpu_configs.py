@@ -74,9 +74,9 @@ def test_fft4096_kernel_indices_and_image(hop, in_kind, round_frames, monkeypatc
     last stage): [frame][bin] indices within 1 LSB of the checker; the image it writes itself, at both round sizes, with
     a band that starts and ends inside a group of four bins, equals the colour map applied to those indices.  A hop that
     is not a multiple of four samples cannot take that kernel's 16-byte sample loads; the three-pass kernel would serve
-    it, but it transforms two frames at once and at 4096 points the recurrence factors let a full-scale frame leave
-    a trace of -96 dB in its partner, above the display floor: such a context takes the general kernel, one frame per
-    transform (same indices within 1 LSB)."""
+    it, but with two frames per transform the recurrence factors at 4096 points let a full-scale frame leave a trace
+    of -96 dB in its partner, above the display floor: such a context takes that kernel's one-frame-per-transform
+    flavour (same indices within 1 LSB)."""
     n = 4096
     rng = np.random.default_rng(7000 + hop)
     L = n + hop * 700 + 3
@@ -94,7 +94,7 @@ def test_fft4096_kernel_indices_and_image(hop, in_kind, round_frames, monkeypatc
     with plugin_engine(n, hop, **kw) as eng:
         got = eng.stft(src)
         route = eng.kernel_route()
-    assert route == ("stft4096_kernel" if hop % 4 == 0 else "stft_general_kernel<float>"), route
+    assert route == ("stft4096_kernel" if hop % 4 == 0 else "stft_mw_kernel<4096,single>"), route
     d = np.abs(got.astype(np.int16) - ref.astype(np.int16))
     d = np.minimum(d, 256 - d)
     assert got.shape == ref.shape and d.max() <= 1 and (d != 0).mean() < 0.02
@@ -109,7 +109,7 @@ def test_fft4096_kernel_indices_and_image(hop, in_kind, round_frames, monkeypatc
             assert route == "stft4096_kernel<image>:rgba", route
             assert img.shape == want.shape and np.array_equal(img, want)          # same arithmetic, same indices
         else:
-            assert "mw" not in route, route
+            assert route == "stft_mw_kernel<4096,single>:u8 + colorize_kernel", route
             assert img.shape == want.shape and np.array_equal(img, want)
 
 

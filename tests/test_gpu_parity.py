@@ -439,6 +439,20 @@ def test_one_frame_per_transform_where_pairing_would_leak():
     want = 20.0 * np.log10(np.maximum(mags.astype(np.float64), 1e-12))
     near = mags > mags.max(axis=1, keepdims=True) * 10 ** (-75 / 20)
     assert np.abs(db - want)[near].max() <= 0.01
+    # the other sizes: the three-pass kernel has the same flavour (2048 points, rectangular window; float32 dB at 512)
+    y = x[:2048 + 512 * 300 + 1]
+    ref = oracle.plugin_get_frequencies(y, 2048, 1536, window="rectangular")
+    with plugin_engine(2048, 512, F.ARITH_FAST_F32, window="rectangular") as eng:
+        got = eng.stft(y)
+        assert eng.kernel_route() == "stft_mw_kernel<2048,single>"
+    assert got.shape == ref.shape and cyc_diff(got, ref).max() <= 1 and (got == ref).mean() > 0.98
+    _, mags, _, _ = oracle.plugin_get_frequencies(y, 512, 384, want_mags=True)
+    with plugin_engine(512, 128, F.ARITH_FAST_F32, out_kind=F.OUT_F32_DB) as eng:
+        db = eng.stft(y)
+        assert eng.kernel_route() == "stft_mw_kernel<512,single>"
+    want = 20.0 * np.log10(np.maximum(mags.astype(np.float64), 1e-12))
+    near = mags > mags.max(axis=1, keepdims=True) * 10 ** (-75 / 20)
+    assert np.abs(db - want)[near].max() <= 0.01
 
 
 @pytest.mark.parametrize("flavour", ["single", "bank"])
@@ -723,9 +737,9 @@ def test_plugin_scaled_get_frequencies(case):
 def test_scaled_frequencies_stay_on_the_float32_kernels(n, hop, scale):
     """A non-linear frequency scale in the float32 arithmetic.  1024 points: the index kernel gathers the two taps of
     every output bin itself.  Other sizes: magnitudes from the fast transform kernels, then the
-    filter-bank kernel; the general kernel is not involved -- except at 4096 points, where the only fast kernel with a
-    magnitude output transforms two frames at once and the recurrence factors would let a full-scale frame leave a
-    trace above the display floor in its partner.  Indices within 1 LSB of the checker's, the image is the
+    filter-bank kernel; the general kernel is not involved (at 4096 points, where the recurrence factors would let a
+    full-scale frame leave a trace above the display floor in a partner, the magnitudes come from the
+    one-frame-per-transform flavour).  Indices within 1 LSB of the checker's, the image is the
     colour map applied to the same arithmetic's indices (any band), and a NaN sample turns every bin of the frames it
     touches into index 0."""
     rng = np.random.default_rng(n + 5)
@@ -743,7 +757,8 @@ def test_scaled_frequencies_stay_on_the_float32_kernels(n, hop, scale):
     if n == 1024:
         assert route == "stft1024_u8_kernel<table,bank>", route
     else:
-        assert ("general" not in route or n == 4096) and "filterbank_index_kernel" in route, route
+        assert "general" not in route and "filterbank_index_kernel" in route, route
+        assert n != 4096 or "stft_mw_kernel<4096,single>:mag" in route, route
     d = cyc_diff(got, ref)
     assert got.shape == ref.shape and d.max() <= 1 and (d != 0).mean() < 0.02, (d.max(), (d != 0).mean())
     lut = (np.arange(1024, dtype=np.uint32) * 5 % 256).astype(np.uint8)
@@ -753,7 +768,7 @@ def test_scaled_frequencies_stay_on_the_float32_kernels(n, hop, scale):
         eng.set_colormap(lut)
         img = eng.stft(x)
         route = eng.kernel_route()
-    assert ("general" not in route or n == 4096) and "colorize_kernel" in route, route
+    assert "general" not in route and "colorize_kernel" in route, route
     assert n != 1024 or route == "stft1024_u8_kernel<table,bank>:u8 + colorize_kernel", route
     assert np.array_equal(img, lut.reshape(256, 4)[got[:, lo:hi].T[::-1]])
     # an index band that does not start and end on a group of four bins: through the magnitude plane at every size
