@@ -531,13 +531,16 @@ static int launch_range(sono_ctx* c, const StftParams& q_in, const IndexScratch&
   const bool rgba = q_in.out_kind == SONO_OUT_RGBA8;
   // A non-linear frequency scale at 1024 points: the float32 index kernel applies the two taps per output bin itself
   // (whole groups of four bins, as for the linear scale; the image goes through a chunk of indices, whose band is
-  // rounded outwards).  Other sizes, ragged index bands and tables whose pairs would leak take the route through a
-  // plane of magnitudes further down.
-  const bool fb_fused = q_in.fb_bin && !exact && c->fb_fast_mode && c->d_fb_packed && q_in.n == 1024 && c->pair_idx_ok &&
+  // rounded outwards); at 512 / 2048 / 4096 points the three-pass kernel does.  Ragged index bands, and 1024-point
+  // tables whose pairs would leak, take the route through a plane of magnitudes further down.
+  const bool fb_1024 = q_in.n == 1024 && c->fb_fast_mode && c->pair_idx_ok;
+  const bool fb_mw = q_in.n != 1024 && c->fb_mw_ok;  // (the three-pass kernel: 512 / 2048 / 4096 points, pairs or single frames)
+  const bool fb_fused = q_in.fb_bin && !exact && c->d_fb_packed && (fb_1024 || fb_mw) &&
                         (rgba || (q_in.out_kind == SONO_OUT_U8_INDEX && !((q_in.bin_lo | q_in.bin_hi | q_in.out_bins | q_in.out_bin0) & 3u)));
   StftParams q = q_in;
   if (fb_fused) {
-    q.fast_mode = c->fb_fast_mode;
+    q.fast_mode = fb_1024 ? c->fb_fast_mode : 0;
+    q.mw_ok = fb_mw ? 1u : 0u;
     q.fb_packed = c->d_fb_packed;
   }
   StftParams qq = q;

@@ -99,12 +99,17 @@ __device__ __forceinline__ void group_sync() {
 // (StftParams::pair_idx_ok) or float32 outputs would carry it (pair_exact).
 // OUT: kOutU8 [frame][bin] colour indices; kOutDb / kOutMag [frame][bin] float32 20*log10(m) / m; kOutFeatures
 // [frame] spectral peak (strict-> first-wins argmax of |X|^2 over the band and that bin's colour index).
-constexpr int kOutU8 = 0, kOutFeatures = 2, kOutDb = 3, kOutMag = 4;
+// kOutU8Bank: colour indices on a non-linear frequency scale: out[y] = m[tap[y]] * w0[y] + m[tap[y] + 1] * w1[y] over the
+// frame's magnitudes (spectrogram.esm.js:479-488 with the two non-zero weights of a row), then the quantiser.  The
+// epilogue leaves the magnitudes in the planes (frame A in the real one, frame B in the imaginary one, each in the cells
+// of the bins below N/2, which only their own thread has read) and a second sweep gathers the taps.
+constexpr int kOutU8 = 0, kOutFeatures = 2, kOutDb = 3, kOutMag = 4, kOutU8Bank = 5;
 template <int LOG2N, int G, int M, bool PLUGIN, typename In, int OUT>
 __global__ __launch_bounds__((1 << LOG2N) / 16 * G, 4) void stft_mw_kernel(StftParams p, FastScale fs) {
   constexpr int N = 1 << LOG2N, TN = N / 16, CB = LOG2N - 8, NC = 1 << CB, SETS = 16 / NC;
   constexpr bool FEAT = OUT == kOutFeatures, FLT = OUT == kOutDb || OUT == kOutMag;
-  constexpr bool SINGLE = M < 0;
+  constexpr bool SINGLE = M < 0, BANK = OUT == kOutU8Bank;
+  __shared__ int s_bad[BANK ? G * 2 : 1];  // BANK: a frame of the group's pair has an infinite or NaN magnitude
   static_assert(!(SINGLE && FEAT), "the feature records come from the paired flavour (its marks cover the cross-talk)");
   constexpr int kWavesPerGroup = TN > 64 ? TN / 64 : 1;
   __shared__ float s_best[FEAT ? G * kWavesPerGroup * 2 : 1];   // FEAT, transforms wider than a wavefront:
@@ -222,6 +227,9 @@ __global__ __launch_bounds__((1 << LOG2N) / 16 * G, 4) void stft_mw_kernel(StftP
         if constexpr (FEAT) zmax = fmaxf(zmax, fmaxf(fabsf(re[s * NC + c]), fabsf(im[s * NC + c])));
       }
     }
+    if constexpr (BANK) {
+      if (t == 0) s_bad[2 * grp] = s_bad[2 * grp + 1] = 0;
+    }
     group_sync<TN>();
     // epilogue: thread handles the bin quads q = t, t + TN (N/8 quads per frame)
     const uint64_t row_a = (p.col0 + f0) * p.out_bins, row_b = row_a + p.out_bins;
@@ -233,7 +241,7 @@ __global__ __launch_bounds__((1 << LOG2N) / 16 * G, 4) void stft_mw_kernel(StftP
 #pragma unroll
     for (int m = 0; m < (N / 8) / TN; ++m) {
       const int k = 4 * (t + TN * m);
-      if (k >= (int)p.bin_lo && k < (int)p.bin_hi) {
+      if (BANK || (k >= (int)p.bin_lo && k < (int)p.bin_hi)) {  // (BANK: a tap may lie outside the band)
         uint32_t wa = 0, wb = 0;
         float fa[4] = {0, 0, 0, 0}, fb[4] = {0, 0, 0, 0};
         const int cellZ = k + (k >> 5);  // + B (k is a multiple of 4)
@@ -251,6 +259,9 @@ __global__ __launch_bounds__((1 << LOG2N) / 16 * G, 4) void stft_mw_kernel(StftP
       next_b = __builtin_amdgcn_fmed3f(mb, best_b, next_b);                    \
       if (ma > best_a) { best_a = ma; kbest_a = k + B; }                       \
       if (mb > best_b) { best_b = mb; kbest_b = k + B; }                       \
+    } else if constexpr (BANK) {                                               \
+      fa[B] = __builtin_amdgcn_sqrtf(ma); /* (1 ulp: an index step is 0.3 dB) */ \
+      fb[B] = __builtin_amdgcn_sqrtf(mb);                                      \
     } else if constexpr (FLT) {                                                \
       fa[B] = OUT == kOutDb ? fast_db(ma, fs) : __builtin_sqrtf(ma) * mag_scale; \
       fb[B] = OUT == kOutDb ? fast_db(mb, fs) : __builtin_sqrtf(mb) * mag_scale; \
@@ -262,6 +273,19 @@ __global__ __launch_bounds__((1 << LOG2N) / 16 * G, 4) void stft_mw_kernel(StftP
         SONO_BIN(0) SONO_BIN(1) SONO_BIN(2) SONO_BIN(3)
 #undef SONO_BIN
         const uint32_t col = k - p.out_bin0;
+        if constexpr (BANK) {
+          // magnitudes are >= +0, so as bit patterns infinities and NaNs (of either sign) sort highest
+          uint32_t top_a = 0, top_b = 0;
+#pragma unroll
+          for (int B = 0; B < 4; ++B) {
+            s_re[cellZ + B] = fa[B];
+            if (!SINGLE) s_im[cellZ + B] = fb[B];
+            top_a = max(top_a, __float_as_uint(fa[B]));
+            top_b = max(top_b, __float_as_uint(fb[B]));
+          }
+          if (top_a >= 0x7f800000u) s_bad[2 * grp] = 1;
+          if (!SINGLE && top_b >= 0x7f800000u) s_bad[2 * grp + 1] = 1;
+        } else
         if constexpr (FLT) {
           float* o = reinterpret_cast<float*>(p.out) + col;
           if (st_a) *reinterpret_cast<float4*>(o + row_a) = make_float4(fa[0], fa[1], fa[2], fa[3]);
@@ -269,6 +293,43 @@ __global__ __launch_bounds__((1 << LOG2N) / 16 * G, 4) void stft_mw_kernel(StftP
         } else if constexpr (!FEAT) {
           if (st_a) *reinterpret_cast<uint32_t*>(out + row_a + col) = wa;
           if (!SINGLE && active) *reinterpret_cast<uint32_t*>(out + row_b + col) = wb;
+        }
+      }
+    }
+    if constexpr (BANK) {
+      if (t == 0) s_re[pad(N / 2)] = s_im[pad(N / 2)] = 0.0f;  // what a tap at the last bin reads as its neighbour
+      group_sync<TN>();
+      // one infinite or NaN magnitude turns every output bin of its frame NaN (index 0): the reference's row sum visits
+      // every bin of the spectrum, and 0 * inf and 0 * NaN are NaN
+      const uint32_t keep_a = s_bad[2 * grp] ? 0u : ~0u, keep_b = s_bad[2 * grp + 1] ? 0u : ~0u;
+      FastScale fm = fs;
+      fm.a = 2.0f * fs.a;  // the quantiser on a magnitude instead of its square: log2(v^2) = 2 log2(v)
+      const char* bank = reinterpret_cast<const char*>(p.fb_packed);
+#pragma unroll 1
+      for (int m = 0; m < (N / 8) / TN; ++m) {
+        int quad = t + TN * m;
+        asm volatile("" : "+v"(quad));  // (the table reads stay inside the frame loop)
+        const int y0 = 4 * quad;
+        const int4 tp = *reinterpret_cast<const int4*>(bank + 16 * quad);
+        const float4 u0 = *reinterpret_cast<const float4*>(bank + 2 * N + 16 * quad);
+        const float4 u1 = *reinterpret_cast<const float4*>(bank + 4 * N + 16 * quad);
+        const int taps[4] = {tp.x, tp.y, tp.z, tp.w};
+        const float c0[4] = {u0.x, u0.y, u0.z, u0.w}, c1[4] = {u1.x, u1.y, u1.z, u1.w};
+        uint32_t wa = 0, wb = 0;
+#pragma unroll
+        for (int B = 0; B < 4; ++B) {
+          const int q0 = pad(taps[B]), q1 = pad(taps[B] + 1);
+          const float va = __builtin_fmaf(s_re[q1], c1[B], s_re[q0] * c0[B]);
+          const float vb = SINGLE ? 0.0f : __builtin_fmaf(s_im[q1], c1[B], s_im[q0] * c0[B]);
+          if (B == 0) { wa = fast_plugin_byte<0>(va, fm, wa); wb = fast_plugin_byte<0>(vb, fm, wb); }
+          if (B == 1) { wa = fast_plugin_byte<1>(va, fm, wa); wb = fast_plugin_byte<1>(vb, fm, wb); }
+          if (B == 2) { wa = fast_plugin_byte<2>(va, fm, wa); wb = fast_plugin_byte<2>(vb, fm, wb); }
+          if (B == 3) { wa = fast_plugin_byte<3>(va, fm, wa); wb = fast_plugin_byte<3>(vb, fm, wb); }
+        }
+        if (y0 >= (int)p.bin_lo && y0 < (int)p.bin_hi) {
+          const uint32_t col = y0 - p.out_bin0;
+          if (st_a) *reinterpret_cast<uint32_t*>(out + row_a + col) = wa & keep_a;
+          if (!SINGLE && active) *reinterpret_cast<uint32_t*>(out + row_b + col) = wb & keep_b;
         }
       }
     }
@@ -348,6 +409,9 @@ int launch_stft_mw(const StftParams& p, void* stream_v) {
   // one frame per transform where two would not do: float32 outputs under an asymmetric table (StftParams::pair_exact),
   // colour indices under a table whose cross-talk could show (StftParams::pair_idx_ok)
   const bool single = (flt && !p.pair_exact) || (u8 && !p.pair_idx_ok);
+  // a non-linear frequency scale: colour indices only, plugin quantiser
+  const bool bank = p.fb_packed != nullptr;
+  if (bank && (!u8 || p.scale_mode != SONO_SCALE_PLUGIN_DB)) return 1;
   if (feat) {  // features do not use the output row layout
     if ((p.n != 512 && p.n != 2048 && p.n != 4096) || !p.mw_ok || !p.twiddles || (p.bin_lo & 3) || (p.bin_hi & 3) ||
         p.bin_lo >= p.bin_hi || p.nframes < 2)
@@ -378,6 +442,8 @@ int launch_stft_mw(const StftParams& p, void* stream_v) {
 #define SONO_MW_M(L2, GR, PL, In)                                                                          \
   do {                                                                                                     \
     if (feat) SONO_MW(L2, GR, 0, PL, In, kOutFeatures);                                                    \
+    else if (bank && single) SONO_MW(L2, GR, -1, true, In, kOutU8Bank);                                    \
+    else if (bank) SONO_MW(L2, GR, 0, true, In, kOutU8Bank);                                               \
     else if (single && p.out_kind == SONO_OUT_F32_DB) SONO_MW(L2, GR, -1, PL, In, kOutDb);                 \
     else if (single && p.out_kind == SONO_OUT_F32_MAG) SONO_MW(L2, GR, -1, PL, In, kOutMag);               \
     else if (single) SONO_MW(L2, GR, -1, PL, In, kOutU8);                                                  \
@@ -400,6 +466,10 @@ int launch_stft_mw(const StftParams& p, void* stream_v) {
 #undef SONO_MW_IN
 #undef SONO_MW_M
 #undef SONO_MW
+  if (bank)
+    note_kernel(single ? (p.n == 4096 ? "stft_mw_kernel<4096,single,bank>" : p.n == 2048 ? "stft_mw_kernel<2048,single,bank>" : "stft_mw_kernel<512,single,bank>")
+                       : (p.n == 4096 ? "stft_mw_kernel<4096,bank>" : p.n == 2048 ? "stft_mw_kernel<2048,bank>" : "stft_mw_kernel<512,bank>"));
+  else
   note_kernel(single ? (p.n == 4096 ? "stft_mw_kernel<4096,single>" : p.n == 2048 ? "stft_mw_kernel<2048,single>" : "stft_mw_kernel<512,single>")
                      : (p.n == 4096 ? "stft_mw_kernel<4096>" : p.n == 2048 ? "stft_mw_kernel<2048>" : "stft_mw_kernel<512>"));
   return hipGetLastError() == hipSuccess ? SONO_OK : SONO_ERR_DEVICE;

@@ -735,11 +735,11 @@ def test_plugin_scaled_get_frequencies(case):
 @pytest.mark.parametrize("n,hop", [(1024, 256), (512, 128), (2048, 512), (4096, 1024)])
 @pytest.mark.parametrize("scale", ["mel", "logarithmic"])
 def test_scaled_frequencies_stay_on_the_float32_kernels(n, hop, scale):
-    """A non-linear frequency scale in the float32 arithmetic.  1024 points: the index kernel gathers the two taps of
-    every output bin itself.  Other sizes: magnitudes from the fast transform kernels, then the
-    filter-bank kernel; the general kernel is not involved (at 4096 points, where the recurrence factors would let a
-    full-scale frame leave a trace above the display floor in a partner, the magnitudes come from the
-    one-frame-per-transform flavour).  Indices within 1 LSB of the checker's, the image is the
+    """A non-linear frequency scale in the float32 arithmetic: the index kernel (1024 points) or the three-pass kernel
+    (other sizes) gathers the two taps of every output bin itself; an index band that is not made of whole groups of
+    four bins goes through a plane of magnitudes and the filter-bank kernel.  The general kernel is not involved (at
+    4096 points, where the recurrence factors would let a full-scale frame leave a trace above the display floor in a
+    partner, the three-pass kernel transforms one frame at a time).  Indices within 1 LSB of the checker's, the image is the
     colour map applied to the same arithmetic's indices (any band), and a NaN sample turns every bin of the frames it
     touches into index 0."""
     rng = np.random.default_rng(n + 5)
@@ -754,11 +754,9 @@ def test_scaled_frequencies_stay_on_the_float32_kernels(n, hop, scale):
         eng.set_filterbank(*fb)
         got = eng.stft(x)
         route = eng.kernel_route()
-    if n == 1024:
-        assert route == "stft1024_u8_kernel<table,bank>", route
-    else:
-        assert "general" not in route and "filterbank_index_kernel" in route, route
-        assert n != 4096 or "stft_mw_kernel<4096,single>:mag" in route, route
+    fused = {1024: "stft1024_u8_kernel<table,bank>", 512: "stft_mw_kernel<512,bank>", 2048: "stft_mw_kernel<2048,bank>",
+             4096: "stft_mw_kernel<4096,single,bank>"}[n]
+    assert route == fused, route
     d = cyc_diff(got, ref)
     assert got.shape == ref.shape and d.max() <= 1 and (d != 0).mean() < 0.02, (d.max(), (d != 0).mean())
     lut = (np.arange(1024, dtype=np.uint32) * 5 % 256).astype(np.uint8)
@@ -769,15 +767,15 @@ def test_scaled_frequencies_stay_on_the_float32_kernels(n, hop, scale):
         img = eng.stft(x)
         route = eng.kernel_route()
     assert "general" not in route and "colorize_kernel" in route, route
-    assert n != 1024 or route == "stft1024_u8_kernel<table,bank>:u8 + colorize_kernel", route
+    assert route == fused + ":u8 + colorize_kernel", route
     assert np.array_equal(img, lut.reshape(256, 4)[got[:, lo:hi].T[::-1]])
     # an index band that does not start and end on a group of four bins: through the magnitude plane at every size
     with plugin_engine(n, hop, F.ARITH_FAST_F32, bin_lo=lo, bin_hi=hi) as eng:
         eng.set_filterbank(*fb)
         band = eng.stft(x)
         assert "filterbank_index_kernel" in eng.kernel_route()
-    db = cyc_diff(band, got[:, lo:hi])     # (1024 points: two float32 routes, which may round a borderline bin differently)
-    assert db.max() <= (1 if n == 1024 else 0) and (db != 0).mean() < 0.01
+    db = cyc_diff(band, got[:, lo:hi])     # (two float32 routes, which may round a borderline bin differently)
+    assert db.max() <= 1 and (db != 0).mean() < 0.01
     xn = x.copy()
     xn[n + 5 * hop + 17] = np.nan
     with plugin_engine(n, hop, F.ARITH_FAST_F32) as eng:
