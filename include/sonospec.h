@@ -321,7 +321,8 @@ int sono_set_tables(sono_ctx* ctx, const float* window /* fft_n */, const double
 /* Installs (or, with bin == NULL, removes) the filter bank that getFrequencies applies between the magnitudes
  * and the quantiser for a non-linear `scale` (applyFilterBank, spectrogram.esm.js:479-488,509-530): fft_n/2
  * filters of two taps each, from sono_filterbank_table or from the host's own arithmetic.  Plugin scale mode
- * only.  With a filter bank the transform runs in the general kernel. */
+ * only.  In the float32 arithmetic the transform kernels gather the two taps themselves (colour indices and images);
+ * in the exact arithmetic, and for float32 / feature outputs, the transform runs in the general kernel. */
 int sono_set_filterbank(sono_ctx* ctx, const int32_t* bin, const double* w0, const double* w1);
 int sono_geometry_of(const sono_ctx* ctx, uint64_t n_samples, sono_geometry* out);
 /* Bytes sono_stft writes for n_samples under the context's out_kind. */
