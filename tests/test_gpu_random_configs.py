@@ -83,7 +83,7 @@ def engine_of(c, out_kind):
     return eng
 
 
-@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("SONO_RANDOM_CASES", "48"))))
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("SONO_RANDOM_CASES", "96"))))
 def test_random_configuration_against_checker(seed):
     rng = np.random.default_rng(1000 + seed)
     c = draw_config(rng)
