@@ -412,7 +412,8 @@ __global__ __launch_bounds__(256) void filterbank_index_kernel(const float* __re
       if (o + 1 >= 0 && o + 1 < (int32_t)half) acc += m[o + 1] * wb[y];
       if (bad) acc = __builtin_nanf("");
       const float x = acc * unscale;  // fast_index takes |X|^2 before the 2/N scaling
-      orow[y] = (uint8_t)fast_index(x * x, fs);
+      // (a negative sum -- negative weights -- has no logarithm: NaN in the reference, index 0)
+      orow[y] = (uint8_t)fast_index(x < 0.0f ? __builtin_nanf("") : x * x, fs);
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();

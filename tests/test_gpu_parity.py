@@ -793,6 +793,44 @@ def test_scaled_frequencies_stay_on_the_float32_kernels(n, hop, scale):
     assert np.array_equal(gi, gn)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,hop", [(1024, 256), (512, 128), (2048, 512), (4096, 1024)])
+def test_filter_bank_taps_at_and_beyond_the_ends_of_the_spectrum(n, hop):
+    """A host may install any two-tap bank (sono_set_filterbank).  Taps at the ends of the spectrum and beyond them
+    -- first tap -1 (only the second one exists), n/2 - 1 (only the first one), further out (neither), random ones
+    in between, a zero weight, a negative weight (its sum has no logarithm: index 0) -- through the float32
+    kernels that gather the taps themselves against the exact arithmetic (general kernel), within 1 LSB."""
+    half = n // 2
+    rng = np.random.default_rng(n)
+    tap = rng.integers(0, half - 1, half).astype(np.int32)
+    w0, w1 = rng.uniform(0.0, 1.0, half), rng.uniform(0.0, 1.0, half)
+    tap[:8] = [-1, half - 1, -2, half, half + 7, -100, 0, half - 2]
+    w0[8], w1[8] = 0.0, 0.0
+    w0[9], w1[9] = -0.5, 0.1
+    L = n + hop * 300 + 5
+    t = np.arange(L, dtype=np.float64)
+    x = (rng.standard_normal(L) * 0.05 + 0.4 * np.sin(t * (0.2 + 0.5 * t / L))).astype(np.float32)
+    out = {}
+    for arith in (F.ARITH_EXACT_F64, F.ARITH_FAST_F32):
+        with plugin_engine(n, hop, arith) as eng:
+            eng.set_filterbank(tap, w0, w1)
+            out[arith] = eng.stft(x)
+            route = eng.kernel_route()
+        assert ("bank" in route) == (arith == F.ARITH_FAST_F32), route
+    ex, fa = out[F.ARITH_EXACT_F64], out[F.ARITH_FAST_F32]
+    d = cyc_diff(fa, ex)
+    assert fa.shape == ex.shape and d.max() <= 1 and (d != 0).mean() < 0.02
+    assert (fa[:, [2, 3, 4, 5, 8]] == ex[:, [2, 3, 4, 5, 8]]).all()       # no tap inside the spectrum, or zero weights
+    assert (fa[:, 9] == 0).mean() > 0.5                                   # (mostly negative sums)
+    # a band that is not made of whole groups of four bins: through the plane of magnitudes, same rules
+    with plugin_engine(n, hop, F.ARITH_FAST_F32, bin_lo=1, bin_hi=half - 2) as eng:
+        eng.set_filterbank(tap, w0, w1)
+        band = eng.stft(x)
+        assert "filterbank_index_kernel" in eng.kernel_route()
+    d = cyc_diff(band, ex[:, 1:half - 2])
+    assert d.max() <= 1 and (d != 0).mean() < 0.02
+
+
 # ------------------------------------------------------------------ the canvas step of drawSpectrogram (:357-381)
 @pytest.mark.gpu
 @pytest.mark.parametrize("case", G.cases("plugin_render"), ids=lambda c: c["id"])
