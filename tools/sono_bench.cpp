@@ -1,5 +1,6 @@
 // Native benchmark / profiling host for libsonospec.so: no Python, no PyTorch, just the C ABI.
-//   sono_bench [seconds=600] [steps=5] [out=u8|rgba|feat] [fft=1024] [hop=256] [path=worker|plugin] [bin_lo bin_hi (0 0 = all)] [arith=fast|exact]
+//   sono_bench [seconds=600] [steps=5] [out=u8|rgba|feat] [fft=1024] [hop=256] [path=worker|plugin] [bin_lo bin_hi (0 0 = all)] [arith=fast|exact] [scale=mel|logarithmic|bark|erb]
+// Environment: SONO_BENCH_WINDOW=<SONO_WIN_* id> selects the plugin path's window (default Hann).
 // Generates a seeded synthetic recording on the host, copies it to the GPU once, runs the worker-path
 // transform `steps` times on device-resident buffers and prints Msamples/s from HIP-event timing.
 #include <cmath>
