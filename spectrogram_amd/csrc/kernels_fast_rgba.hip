@@ -12,7 +12,8 @@
 //     v_permlane16_swap (no memory), the remaining 16 x 16 transposes of each 16-lane row through a 1 KiB block
 //     (16-byte chunks XOR-swizzled by row: stores and row reads both conflict-free), one half of the registers after
 //     the other: 4.25 KiB per wavefront instead of 9;
-//   * the epilogue pairs Z[k] with Z[N-k] in quarters of 128 bins (2 KiB per transform).
+//   * the epilogue sends only the partners Z[N-k] through LDS, in two rounds of eight registers (2 KiB per transform);
+//     Z[k] stays in its lane, and a lane ends up with one dword (four frames) per bin, which is what a ring row takes.
 // LDS: 8 KiB twiddle matrix + 4.5 KiB window + 1 KiB colour map + 16 x 4.25 KiB + 74 KiB slot = 155.5 KiB.
 //
 // Whole 64-byte sectors only: the slot is the ring of sono_image_ring.h (a workgroup owns a contiguous range of frames,
@@ -47,15 +48,8 @@ constexpr int kWinPitch = 36;
 constexpr int kWinBytes = 32 * kWinPitch * 4;
 constexpr int kLutBytes = 1024;
 constexpr int kWaveBytes = 4 * kBlkFloats * 4;       // 4352: four 16-lane rows
-constexpr int kQuarterBytes = kWaveBytes / 2;        // epilogue, per transform: 128 values Z[k], then 128 partners Z[N-k]
-// 128 complex values laid out for the epilogue: value j (8 bytes) of a quarter sits in plane (j >> 1) & 1 at
-// 16 * (j >> 2) + 8 * (j & 1), so that a lane's four consecutive values are one 16-byte read per plane at 16 * lane
-// (conflict-free), and the second plane starts 16 banks after the first so that the 8-byte stores of 16 consecutive
-// lanes cover 32 different banks.
-constexpr int kPlane1 = 512 + 64;
-constexpr int kMirrorOffset = kPlane1 + 512;
-static_assert(2 * kMirrorOffset <= kQuarterBytes, "an epilogue quarter must fit half the wavefront's slice");
-__device__ __forceinline__ int quarter_pos(int j) { return ((j >> 1) & 1) * kPlane1 + (j >> 2) * 16 + (j & 1) * 8; }
+constexpr int kQuarterBytes = kWaveBytes / 2;        // epilogue, per transform: eight rows of 32 partner values (2 KiB)
+static_assert(8 * 32 * 8 <= kQuarterBytes, "an epilogue round must fit half the wavefront's slice");
 constexpr int kSlotBytes = Ring<kRoundFrames>::bytes(512);
 constexpr int kOffWin = kTwBytes, kOffLut = kOffWin + kWinBytes, kOffWave = kOffLut + kLutBytes, kOffSlot = kOffWave + kWaves * kWaveBytes;
 constexpr int kLdsBytes = kOffSlot + kSlotBytes;
@@ -179,7 +173,18 @@ __global__ __launch_bounds__(kWaves * 64, 4) void stft1024_rgba_kernel(StftParam
   Unit cur = locate(0);
   fetch(cur);
   uint32_t fq[2][4] = {};     // indices of the two quarters the next iteration writes out
-  uint32_t pend[2][4] = {};   // indices of iteration 0's epilogue, stored into the slot in iteration 1
+  uint32_t pend[8] = {};      // dwords of iteration 0's epilogue, stored into the slot in iteration 1
+  // Frame group fg (four frames) of round k of this workgroup: one dword into each of the rows of the bins
+  // bin0 + 64*m, m = 0..7 (whole groups of 64 rows outside the band are skipped; the rest of the slot is never read).
+  auto park8 = [&](const uint32_t (&r)[8], uint64_t k, int fg, int bin0) {
+    constexpr int kD = Ring<kRoundFrames>::kDwords, kP = Ring<kRoundFrames>::kPitch;
+    int d = (int)(((uint64_t)(kRoundFrames / 4) * k) % kD) + fg;
+    d -= d >= kD ? kD : 0;
+    uint32_t* row = slot + bin0 * kP + d;
+#pragma unroll
+    for (int m = 0; m < 8; ++m)
+      if (64 * m + 63 >= (int)p.bin_lo && 64 * m < (int)p.bin_hi) row[m * 64 * kP] = r[m];
+  };
   bool pend_active = false;
   for (uint64_t it = 0; it < (rounds + 2) * kTileIters; ++it) {
     const uint64_t round = it / kTileIters;
@@ -240,69 +245,62 @@ __global__ __launch_bounds__(kWaves * 64, 4) void stft1024_rgba_kernel(StftParam
         fft32(re, im);  // X[l + 32*k2]
       }
 
-      // Epilogue in quarters of 128 bins.  For quarter Q the registers k2 = 4Q + r hold Z[k] for k = 128Q + 32r + l and
-      // the registers 28 - 4Q + r hold the partners Z[N - k]; both go to LDS as value k - 128Q of their half of the
-      // quarter buffer, so that a lane's four consecutive bins are two 16-byte reads each.  Lane 0's partner registers
-      // sit one row off: its partner of value 0 is Z[N - 128Q], register (32 - 4Q) mod 32.
+      // Epilogue.  Bin k = l + 32*k2 (k2 < 16) stays in its lane; its partner Z[N - k] sits in lane 32 - l, register
+      // 31 - k2 (lane 0: its own register 32 - k2).  Only the partners travel: two rounds of eight registers (16..23, then
+      // 24..31) through the half-wavefront's 2-KiB buffer, register r0 + j of lane l at [j][l].  Lane 0 stores one row
+      // down and puts register 24 (round 0) / 0 (round 1) into row 7, so that every lane reads [j][(32 - l) mod 32].
+      // Byte 0 / 1 of w[k2]: the colour indices of the transform's frames A / B at that bin.
       const bool shifted = cur.shifted;
       int lq = l;
       asm volatile("" : "+v"(lq));
-      unsigned char* zw = qbuf + quarter_pos(lq);                          // value 32r + l: + 128r
-      unsigned char* pw = qbuf + kMirrorOffset + quarter_pos(32 - lq);     // partner 32(3-r) + 32 - l: + 128(3-r)
-      // lane 0's partner of row 0 would be value 128, which nobody reads: it stores value 0 there instead
-      unsigned char* pw0 = lq == 0 ? qbuf + kMirrorOffset : pw + 128 * 3;
-      const unsigned char* zr = qbuf + 16 * lq;
-      uint32_t wa2[2], wb2[2];
+      const bool lane0 = lq == 0;
+      unsigned char* wr = qbuf + 8 * lq - (lane0 ? 256 : 0);
+      unsigned char* wr0 = lane0 ? qbuf + 7 * 256 : qbuf + 8 * lq;
+      const unsigned char* rd = qbuf + 8 * ((32 - lq) & 31);
+      uint32_t w[16];
 #pragma unroll
-      for (int Q = 0; Q < 4; ++Q) {
+      for (int R = 0; R < 2; ++R) {
+        const int r0 = 16 + 8 * R, rx = (24 + 8 * R) & 31;
+        *reinterpret_cast<float2*>(wr0) = lane0 ? make_float2(re[rx], im[rx]) : make_float2(re[r0], im[r0]);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int kl = 4 * Q + r, km = 28 - 4 * Q + r, k0 = (32 - 4 * Q) & 31;
-          *reinterpret_cast<float2*>(zw + 128 * r) = make_float2(re[kl], im[kl]);
-          if (r == 0) *reinterpret_cast<float2*>(pw0) = lq == 0 ? make_float2(re[k0], im[k0]) : make_float2(re[km], im[km]);
-          else *reinterpret_cast<float2*>(pw + 128 * (3 - r)) = make_float2(re[km], im[km]);
-        }
+        for (int j = 1; j < 8; ++j) *reinterpret_cast<float2*>(wr + 256 * j) = make_float2(re[r0 + j], im[r0 + j]);
         wave_sync();
-        const float4 z01 = *reinterpret_cast<const float4*>(zr);
-        const float4 z23 = *reinterpret_cast<const float4*>(zr + kPlane1);
-        const float4 q01 = *reinterpret_cast<const float4*>(zr + kMirrorOffset);
-        const float4 q23 = *reinterpret_cast<const float4*>(zr + kMirrorOffset + kPlane1);
-        uint32_t wa = 0, wb = 0;
-#define SONO_BIN(B, ZR, ZI, PR, PI)                    \
-  {                                                    \
-    const float ar = (ZR) + (PR), ai = (ZI) - (PI);    \
-    const float br = (ZI) + (PI), bi = (PR) - (ZR);    \
-    wa = put_index<PLUGIN, B>(__builtin_fmaf(ar, ar, ai * ai), fs, wa); \
-    wb = put_index<PLUGIN, B>(__builtin_fmaf(br, br, bi * bi), fs, wb); \
-  }
-        SONO_BIN(0, z01.x, z01.y, q01.x, q01.y)
-        SONO_BIN(1, z01.z, z01.w, q01.z, q01.w)
-        SONO_BIN(2, z23.x, z23.y, q23.x, q23.y)
-        SONO_BIN(3, z23.z, z23.w, q23.z, q23.w)
-#undef SONO_BIN
-        wa2[Q & 1] = shifted ? wb : wa;  // an odd last frame was computed as B: it belongs in the A slot
-        wb2[Q & 1] = wb;
-        wave_sync();  // the buffer is rewritten by the next quarter / the next iteration's transpose
-        if (Q & 1) {
-          // before: lanes of transform h hold frames (2h, 2h+1) of the iteration for the bin quads 64P + l (quarter 2P)
-          // and 64P + 32 + l (quarter 2P + 1); after: lane (l, h) holds the quad 64P + l + 32h of all four frames
-          const auto sa = __builtin_amdgcn_permlane32_swap(wa2[0], wa2[1], false, false);
-          const auto sb = __builtin_amdgcn_permlane32_swap(wb2[0], wb2[1], false, false);
-          if (sub == 0) {
-            turn(sa[0], sb[0], sa[1], sb[1], pend[Q >> 1]);
-          } else {
-            uint32_t r4[4];
-            turn(sa[0], sb[0], sa[1], sb[1], r4);
-            park<kRoundFrames>(slot, p, r4, round, kWaves + wave, 32 * (Q - 1) + l + 32 * h);
-          }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int k2 = 15 - 8 * R - j;
+          const float2 q = *reinterpret_cast<const float2*>(rd + 256 * j);
+          const float zr = re[k2], zi = im[k2];
+          const float ar = zr + q.x, ai = zi - q.y;
+          const float br = zi + q.y, bi = q.x - zr;
+          const uint32_t t = put_index<PLUGIN, 0>(__builtin_fmaf(ar, ar, ai * ai), fs, 0u);
+          w[k2] = put_index<PLUGIN, 1>(__builtin_fmaf(br, br, bi * bi), fs, t);
         }
+        wave_sync();  // the buffer is rewritten by the next round / the next iteration's transpose
+      }
+      // an odd last frame was computed as B: it belongs in the A byte (one half-wavefront per launch)
+      if (__builtin_amdgcn_ballot_w64(shifted) != 0) {
+#pragma unroll
+        for (int k2 = 0; k2 < 16; ++k2) w[k2] = shifted ? w[k2] >> 8 : w[k2];
+      }
+      // lanes of transform h hold frames (2h, 2h+1) of the iteration; after the swap lane (l, h) holds all four frames of
+      // the bins l + 32*(2m + h), m = 0..7, as one dword per bin: what a ring row takes
+      uint32_t r8[8];
+#pragma unroll
+      for (int m = 0; m < 8; ++m) {
+        const auto sw = __builtin_amdgcn_permlane32_swap(w[2 * m], w[2 * m + 1], false, false);
+        r8[m] = sw[0] | (sw[1] << 16);
+      }
+      if (sub == 0) {
+#pragma unroll
+        for (int m = 0; m < 8; ++m) pend[m] = r8[m];
+      } else {
+        park8(r8, round, kWaves + wave, lq + 32 * h);
       }
     }
     if (sub == 0) {
       pend_active = cur.active;
-    } else if (pend_active) {  // frame group `wave` of the round: the cells iteration 0 kept
-#pragma unroll
-      for (int P = 0; P < 2; ++P) park<kRoundFrames>(slot, p, pend[P], round, wave, 64 * P + l + 32 * h);
+    } else if (pend_active) {  // frame group `wave` of the round: the dwords iteration 0 kept
+      park8(pend, round, wave, l + 32 * h);
     }
     fetch(nxt);  // unconditional (an inactive unit points at frame 0): no stale values carried round the loop
     cur = nxt;
