@@ -410,10 +410,10 @@ __global__ __launch_bounds__(kWaves * 64) void stft512_kernel(StftParams p, Fast
 // 1024-point image writer (kernels_fast_rgba.hip):
 //   * a round is 256 consecutive frames = two iterations (a wavefront takes 8 frames per iteration, a half-wavefront 4 of
 //     them: frame group 32*iteration + 2*wave + h); a workgroup owns a contiguous range of rounds;
-//   * the transposes go through 16 x 16 blocks (4.25 KiB per wavefront), and the epilogue pairs Z[k] with Z[512 - k] in
-//     four passes of 64 bins, each 16-lane row (one transform) in its own block; after an even and an odd pass
-//     v_permlane16_swap trades between the two transforms of a half-wavefront, so that a lane holds four bins x four
-//     frames: bin quad 32m + 16g + k1 in lane (g, k1);
+//   * the transposes go through 16 x 16 blocks (4.25 KiB per wavefront); in the epilogue only the partners Z[512 - k]
+//     travel through a transform's block (two rounds of eight registers), Z[k] stays in its lane, and
+//     v_permlane16_swap trades between the two transforms of a half-wavefront, so that a lane holds one dword (four
+//     frames) of each of the bins k1 + 16*(2m + g), m = 0..7: what a ring row takes;
 //   * one ring slot (256 bin rows x 272 frames), two barriers per round, both between iterations: iteration 0 writes out
 //     the parts 0, 1 of the round before (wavefront w owns the 16 rows of bins 16w .. 16w+15; a part is 4 rows; a lane
 //     stores 16 bytes of a row's 1-KiB run), transforms, keeps its epilogue's indices in registers and reads the parts
@@ -424,8 +424,8 @@ __global__ __launch_bounds__(kWaves * 64) void stft512_kernel(StftParams p, Fast
 constexpr int kRF = 256;            // frames per workgroup round
 constexpr int kRIters = kRF / 128;  // iterations per round
 constexpr int kWaveBytes = 4 * fast1024::kBlkFloats * 4;  // 4352
-constexpr int kBlkBytes = fast1024::kBlkFloats * 4;       // 1088: a 16-lane row's block; epilogue pass: 64 values + 65 partners
-static_assert((64 + 65) * 8 <= kBlkBytes, "an epilogue pass must fit the row's block");
+constexpr int kBlkBytes = fast1024::kBlkFloats * 4;       // 1088: a 16-lane row's block; epilogue round: 8 rows of 16 partners
+static_assert(8 * 16 * 8 <= kBlkBytes, "an epilogue round must fit the row's block");
 constexpr int kLutBytes = 1024;
 constexpr int kOffWave = kTwBytes + kWinBytes + kLutBytes;
 constexpr int kOffSlot = kOffWave + kWaves * kWaveBytes;
@@ -514,8 +514,19 @@ __global__ __launch_bounds__(kWaves * 64) void stft512_rgba_kernel(StftParams p,
 
   fetch(first_frame(0));
   uint32_t fq[2][4] = {};    // indices of the two parts the next iteration writes out
-  uint32_t pend[2][4] = {};  // indices of iteration 0's epilogue, stored into the slot in iteration 1
+  uint32_t pend[8] = {};     // dwords of iteration 0's epilogue, stored into the slot in iteration 1
   bool pend_active = false;
+  // Frame group fg (four frames) of round k of this workgroup: one dword into each of the rows of the bins
+  // bin0 + 32*m, m = 0..7 (whole groups of 32 rows outside the band are skipped; the rest of the slot is never read).
+  auto park8 = [&](const uint32_t (&r)[8], uint64_t k, int fg, int bin0) {
+    constexpr int kD = Ring<kRF>::kDwords, kP = Ring<kRF>::kPitch;
+    int d = (int)(((uint64_t)(kRF / 4) * k) % kD) + fg;
+    d -= d >= kD ? kD : 0;
+    uint32_t* row = slot + bin0 * kP + d;
+#pragma unroll
+    for (int m = 0; m < 8; ++m)
+      if (32 * m + 31 >= (int)p.bin_lo && 32 * m < (int)p.bin_hi) row[m * 32 * kP] = r[m];
+  };
   for (uint64_t it = 0; it < (rounds + 2) * kRIters; ++it) {
     const uint64_t round = it / kRIters;
     const int sub = (int)(it % kRIters);
@@ -559,71 +570,58 @@ __global__ __launch_bounds__(kWaves * 64) void stft512_rgba_kernel(StftParams p,
       const uint64_t fb = f0 + 4 <= p.nframes ? f0 : p.nframes - 4;
       const int shift = f0 >= p.nframes ? 4 : (int)(f0 - fb);
       const int fg = 32 * sub + 2 * wave + he;
-      // Epilogue in four passes of 64 bins, each row (transform) in its own block: values Z[64P + j] at cell j, partners
-      // Z[512 - 64P - j] at cell 64 + j (j <= 64).  The values are the registers 4P..4P+3 (j = k1 + 16r), the partners the
-      // registers 28-4P..31-4P (j = 64 - k1 - 16r); the partner of j = 0 is one register off: Z[(512 - 64P) mod 512],
-      // register (32 - 4P) mod 32 of lane k1 = 0.  A lane reads the bins 64P + 4*k1 .. +3 of its transform.
-      float2* cz = reinterpret_cast<float2*>(blk);
-      uint32_t wa2[2], wb2[2];
+      // Epilogue.  Bin k = k1 + 16*k2 (k2 < 16) stays in its lane; its partner Z[512 - k] sits in lane 16 - k1 of the same
+      // transform, register 31 - k2 (lane 0: its own register 32 - k2).  Only the partners travel: two rounds of eight
+      // registers (16..23, then 24..31) through the transform's 1-KiB block, register r0 + j of lane k1 at [j][k1].  Lane 0
+      // stores one row down and puts register 24 (round 0) / 0 (round 1) into row 7, so that every lane reads
+      // [j][(16 - k1) mod 16].  Byte 0 / 1 of w[k2]: the colour indices of the transform's frames A / B at that bin.
+      unsigned char* cb = reinterpret_cast<unsigned char*>(blk);
+      const bool lane0 = ke == 0;
+      unsigned char* wr = cb + 8 * ke - (lane0 ? 128 : 0);
+      unsigned char* wr0 = lane0 ? cb + 7 * 128 : cb + 8 * ke;
+      const unsigned char* rd = cb + 8 * ((16 - ke) & 15);
+      uint32_t w[16];
 #pragma unroll
-      for (int P = 0; P < 4; ++P) {
+      for (int R = 0; R < 2; ++R) {
+        const int r0 = 16 + 8 * R, rx = (24 + 8 * R) & 31;
+        *reinterpret_cast<float2*>(wr0) = lane0 ? make_float2(re[rx], im[rx]) : make_float2(re[r0], im[r0]);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          cz[ke + 16 * r] = make_float2(re[4 * P + r], im[4 * P + r]);
-          cz[64 + 64 - ke - 16 * r] = make_float2(re[28 - 4 * P + r], im[28 - 4 * P + r]);
-        }
-        if (ke == 0) cz[64] = make_float2(re[(32 - 4 * P) & 31], im[(32 - 4 * P) & 31]);
+        for (int j = 1; j < 8; ++j) *reinterpret_cast<float2*>(wr + 128 * j) = make_float2(re[r0 + j], im[r0 + j]);
         wave_sync();
-        const float4 z01 = *reinterpret_cast<const float4*>(cz + 4 * ke);
-        const float4 z23 = *reinterpret_cast<const float4*>(cz + 4 * ke + 2);
-        const float4 q01 = *reinterpret_cast<const float4*>(cz + 64 + 4 * ke);
-        const float4 q23 = *reinterpret_cast<const float4*>(cz + 64 + 4 * ke + 2);
-        uint32_t wa = 0, wb = 0;
-#define SONO_BIN(B, ZR, ZI, PR, PI)                                          \
-  {                                                                          \
-    const float ar = (ZR) + (PR), ai = (ZI) - (PI);                          \
-    const float br = (ZI) + (PI), bi = (PR) - (ZR);                          \
-    wa = put_index<PLUGIN, B>(__builtin_fmaf(ar, ar, ai * ai), fs, wa);      \
-    wb = put_index<PLUGIN, B>(__builtin_fmaf(br, br, bi * bi), fs, wb);      \
-  }
-        SONO_BIN(0, z01.x, z01.y, q01.x, q01.y)
-        SONO_BIN(1, z01.z, z01.w, q01.z, q01.w)
-        SONO_BIN(2, z23.x, z23.y, q23.x, q23.y)
-        SONO_BIN(3, z23.z, z23.w, q23.z, q23.w)
-#undef SONO_BIN
-        wa2[P & 1] = wa;
-        wb2[P & 1] = wb;
-        wave_sync();  // the block is rewritten by the next pass / the next iteration's transpose
-        if (P & 1) {
-          // before: the lanes of transform g hold the frames (fb + 2g, +1) of the bin quads 32m + k1 (even pass) and
-          // 32m + 16 + k1 (odd pass); after: lane (g, k1) holds the quad 32m + 16g + k1 of all four frames
-          const auto sa = __builtin_amdgcn_permlane16_swap(wa2[0], wa2[1], false, false);
-          const auto sb = __builtin_amdgcn_permlane16_swap(wb2[0], wb2[1], false, false);
-          uint32_t w4[4] = {sa[0], sb[0], sa[1], sb[1]};
-          if (shift != 0) {  // the frames this lane owns start at position `shift` of the block
-            const uint32_t c1 = w4[1], c2 = w4[2], c3 = w4[3];
-            w4[0] = shift == 1 ? c1 : shift == 2 ? c2 : c3;
-            w4[1] = shift == 1 ? c2 : c3;
-            w4[2] = c3;
-          }
-          const int kq = 32 * (P >> 1) + 16 * ge + ke;
-          if (sub == 0) {
-            turn(w4[0], w4[1], w4[2], w4[3], pend[P >> 1]);
-          } else {
-            uint32_t r4[4];
-            turn(w4[0], w4[1], w4[2], w4[3], r4);
-            park<kRF>(slot, p, r4, round, fg, kq);
-          }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int k2 = 15 - 8 * R - j;
+          const float2 q = *reinterpret_cast<const float2*>(rd + 128 * j);
+          const float zr = re[k2], zi = im[k2];
+          const float ar = zr + q.x, ai = zi - q.y;
+          const float br = zi + q.y, bi = q.x - zr;
+          const uint32_t t = put_index<PLUGIN, 0>(__builtin_fmaf(ar, ar, ai * ai), fs, 0u);
+          w[k2] = put_index<PLUGIN, 1>(__builtin_fmaf(br, br, bi * bi), fs, t);
         }
+        wave_sync();  // the block is rewritten by the next round / the next iteration's transpose
+      }
+      // the lanes of transform g hold the frames (fb + 2g, +1); after the swap lane (g, k1) holds all four frames of the
+      // bins k1 + 16*(2m + g), m = 0..7, as one dword per bin: what a ring row takes.  At the end of the recording the
+      // frames this lane owns start at byte `shift` of the dword.
+      uint32_t r8[8];
+#pragma unroll
+      for (int m = 0; m < 8; ++m) {
+        const auto sw = __builtin_amdgcn_permlane16_swap(w[2 * m], w[2 * m + 1], false, false);
+        r8[m] = (sw[0] | (sw[1] << 16)) >> (8 * (shift & 3));
+      }
+      if (sub == 0) {
+#pragma unroll
+        for (int m = 0; m < 8; ++m) pend[m] = r8[m];
+      } else {
+        park8(r8, round, fg, ke + 16 * ge);
       }
     }
     if (sub == 0) {
       pend_active = active;
-    } else if (pend_active) {  // frame group 2*wave + h of the round: the indices iteration 0 kept
+    } else if (pend_active) {  // frame group 2*wave + h of the round: the dwords iteration 0 kept
       int lane_e = lane;
       asm volatile("" : "+v"(lane_e));
-#pragma unroll
-      for (int m = 0; m < 2; ++m) park<kRF>(slot, p, pend[m], round, 2 * wave + (lane_e >> 5), 32 * m + (lane_e & 31));
+      park8(pend, round, 2 * wave + (lane_e >> 5), lane_e & 31);
     }
     fetch(first_frame(it + 1));  // unconditional: a half with nothing of its own reads the last block of the recording
     if (sub == 0) {
