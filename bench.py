@@ -103,10 +103,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-variants", action="store_true")
     ap.add_argument("--files", type=int, default=-1,
-                    help="per-file batch: number of 5 s x 500 kHz int16 files over all ranks (-1: 400 per rank, 0: skip; "
-                         "BASELINE's configuration is 10000)")
+                    help="per-file batch: number of 5 s x 500 kHz int16 files over all ranks (-1: 1250 per rank, which on "
+                         "8 GPUs is BASELINE's 10000; 0: skip)")
     ap.add_argument("--rehearse", action="store_true",
-                    help="multi-rank dry run on a box with one GPU: every rank uses cuda:0 and the ranks meet over gloo")
+                    help="multi-rank dry run on a box with one GPU: every rank uses cuda:0")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -128,11 +128,11 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
+        # The ranks exchange two scalars (the slowest rank's wall time) and meet at barriers; no tensor ever crosses
+        # GPUs (files and spans are independent), so the group is gloo over the loopback interface and RCCL is not
+        # initialised at all: nothing about the interconnect can fail the run.
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if args.rehearse:
-            dist.init_process_group("gloo")
-        else:
-            dist.init_process_group("nccl", device_id=dev)
+        dist.init_process_group("gloo")
 
     def barrier():
         torch.cuda.synchronize()
@@ -189,29 +189,36 @@ def main():
 
     wall, kern_ms, out_bytes, geo, checksum = run(args.out, args.steps, args.warmup)
     if world > 1:
-        t = torch.tensor([wall], dtype=torch.float64, device="cpu" if args.rehearse else dev)
+        t = torch.tensor([wall], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall = float(t.item())
     value = world * L * args.steps / wall / 1e6
 
     # ---- per-file batch (BASELINE configs[2]): host memory -> host memory, files sharded over the ranks
     files_res = None
-    n_files = 400 * world if args.files < 0 else args.files
+    n_files = 1250 * world if args.files < 0 else args.files
     if n_files > 0:
         from spectrogram_amd import sharding
         FL, FRATE = 2_500_000, 500000                       # 5 s x 500 kHz
         rng = np.random.default_rng(7)
-        t = np.arange(FL, dtype=np.float64)
-        bufs = []
-        for b in range(4):                                   # four distinct recordings, reused
+        bases = []
+        for b in range(4):                                   # four base recordings ...
             v = rng.standard_normal(FL) * 0.01
             for p0 in range(10000 * (b + 1), FL - 3000, 40000):   # 5 ms pulses every 80 ms
                 tt = np.arange(2500, dtype=np.float64)
                 v[p0:p0 + 2500] += 0.3 * np.hanning(2500) * np.sin(2 * np.pi * (80e3 * tt / FRATE - 0.5 * 45e3 / 2500 * tt * tt / FRATE))
-            bufs.append(np.round(np.clip(v, -1, 1) * 32767).astype(np.int16))
-        del t
+            bases.append(np.round(np.clip(v, -1, 1) * 32767).astype(np.int16))
+
+        def file_content(i):
+            """File i: every file differs from every other one (a base recording rotated by a file-specific number of
+            samples, with the file index written into its first two samples)."""
+            v = np.roll(bases[i % 4], 4099 * (i // 4 + 1) % FL)
+            v[0], v[1] = np.int16(i & 0x7fff), np.int16((i >> 15) & 0x7fff)
+            return v
+
         sizes = [FL] * n_files
         mine = sharding.assign_files(sizes, world)[rank]
+        content = {i: file_content(i) for i in mine}        # this rank's files, in host memory before the clock starts
         digest = lambda o: int(o[:: 4099].astype(np.int64).sum())          # a sparse checksum of every output
         fkw = dict(fft_n=FFT_N, hop=HOP, window_id=F.WIN_WORKER_HANN, scale_mode=F.SCALE_WORKER_LOG5,
                    frame_rule=F.FRAMES_WORKER_COMPAT, twiddle_mode=F.TW_ACCURATE, arith=F.ARITH_FAST_F32, in_kind=F.IN_I16,
@@ -219,33 +226,42 @@ def main():
         # (more than one rank: each binds to the CPUs next to its GPU before its page-locked buffers are allocated)
         numa = sharding.bind_to_gpu_numa(local_rank) if world > 1 and not args.rehearse else None
         with sharding.FilePipeline(FL, slots=3, copy=False, **fkw) as pipe:
-            for _ in pipe.run([(i, bufs[i % 4]) for i in mine[:6]]):
+            for _ in pipe.run([(i, content[i]) for i in mine[:6]]):
                 pass
             barrier()
             t0 = time.perf_counter()
-            sums, my_s = sharding.run_file_shard(sizes, rank, world, lambda i: bufs[i % 4], pipe, digest)
+            sums, my_s = sharding.run_file_shard(sizes, rank, world, lambda i: content[i], pipe, digest)
             barrier()
             wall_f = time.perf_counter() - t0
+        # each rank renders the first and the last file of its share once more, one synchronous call each through a
+        # fresh context, and compares with what its pipeline delivered
+        recheck_ok = True
+        if mine:
+            with E.Engine(**fkw) as chk:
+                for i in sorted({mine[0], mine[-1]}):
+                    recheck_ok = recheck_ok and digest(chk.stft(content[i]).reshape(-1).view(np.uint8)) == sums[i]
+        del content
         if world > 1:
-            tf = torch.tensor([wall_f], dtype=torch.float64, device="cpu" if args.rehearse else dev)
+            tf = torch.tensor([wall_f], dtype=torch.float64)
             dist.all_reduce(tf, op=dist.ReduceOp.MAX)
             wall_f = float(tf.item())
-        gathered = sharding.gather_results((rank, len(mine), my_s, sums, numa))
+        gathered = sharding.gather_results((rank, len(mine), my_s, sums, numa, recheck_ok))
         if rank == 0:
             allsums = {}
-            for _, _, _, sm, _ in gathered:
-                allsums.update(sm)
-            ref4 = [allsums[i] for i in range(min(4, n_files))]
+            for g_ in gathered:
+                allsums.update(g_[3])
             files_res = {
-                "workload": "%d files x %d int16 samples (5 s x 500 kHz), host memory to host memory, worker render to %s, "
-                            "files sharded over %d rank(s) by size, 3 overlapped contexts per rank" % (
+                "workload": "%d files x %d int16 samples (5 s x 500 kHz), every file different, host memory to host memory, worker "
+                            "render to %s, files sharded over %d rank(s) by size, 3 overlapped contexts per rank" % (
                                 n_files, FL, "RGBA8" if args.out == "rgba" else "uint8 indices", world),
                 "files": n_files, "seconds": round(wall_f, 4), "files_per_s": round(n_files / wall_f, 1),
                 "msamples_per_s": round(n_files * FL / wall_f / 1e6, 1),
-                "per_rank": [{"rank": r, "files": nf, "seconds": round(s, 4), "msamples_per_s": round(nf * FL / s / 1e6, 1) if s > 0 else None,
-                              "numa_node": nn}
-                             for r, nf, s, _, nn in gathered],
-                "outputs_consistent": len(allsums) == n_files and all(allsums[i] == ref4[i % 4] for i in range(n_files)),
+                "per_rank": [{"rank": r, "files": nf, "seconds": round(s_, 4), "msamples_per_s": round(nf * FL / s_ / 1e6, 1) if s_ > 0 else None,
+                              "numa_node": nn, "recheck_ok": ok}
+                             for r, nf, s_, _, nn, ok in gathered],
+                # every file delivered exactly once, and every rank's re-rendered files came out the same
+                "outputs_consistent": len(allsums) == n_files and all(g_[5] for g_ in gathered),
+                "distinct_outputs": len(set(allsums.values())),
             }
 
     result = None
@@ -367,7 +383,13 @@ def main():
         import subprocess
         import tempfile
         import oracle
-        cores = min(16, len(os.sched_getaffinity(0)))
+        # Every core this process may run on -- unless the box states its CPU share for one GPU's job in OMP_NUM_THREADS
+        # (on a shared multi-GPU host the affinity mask shows the whole machine, and a pool of that size is not this
+        # job's to use); both numbers are reported.
+        cores_available = len(os.sched_getaffinity(0))
+        share = os.environ.get("OMP_NUM_THREADS", "")
+        cores = min(cores_available, int(share)) if share.isdigit() and int(share) > 0 else cores_available
+        cores_note = ("OMP_NUM_THREADS=%s (this job's CPU share on the box)" % share) if cores < cores_available else "the whole affinity mask"
         # (1) the C restatement of the worker render on `cores` POSIX threads
         probe = x[: 2 * SAMPLE_RATE].cpu().numpy()
         t0 = time.perf_counter()
@@ -381,7 +403,7 @@ def main():
         c_port = {"value": round(len(sample) / dt / 1e6, 2), "unit": "Msamples/s", "cores": cores, "kind": "port",
                   "sample": "first %d s of the same recording (%d samples), RGBA render by the C restatement of "
                             "spectrogramWorker.js (oracle/sono_oracle.c), %d POSIX threads" % (secs, len(sample), cores),
-                  "seconds": round(dt, 2)}
+                  "seconds": round(dt, 2), "cores_available": cores_available, "cores_used": cores, "cores_limit": cores_note}
         result["cpu_baseline"] = c_port
         # (2) the same render in the reference's own language and runtime: the JavaScript restatement under
         #     Node worker_threads, one worker per core, hop-aligned 10 s chunks with a 768-sample halo
@@ -406,18 +428,22 @@ def main():
                               "spectrogramWorker.js (oracle/worker_restatement.js, byte-identical to the reference on its golden "
                               "cases) under Node %s worker_threads, %d workers, 10 s chunks" % (
                                   len(jsample) // SAMPLE_RATE, j["passes"], j["samples"], j["node"], cores),
-                    "seconds": round(j["wall_s"], 2),
-                    "c_port": c_port,
+                    "seconds": round(j["wall_s"], 2), "cores_available": cores_available, "cores_used": cores,
+                    "cores_limit": cores_note, "c_port": c_port,
                 }
                 # how the restatement relates to the reference itself (which cannot travel to this box): both were
-                # timed in the build container on one thread and the same 10 s signal by tools/time_reference.js
+                # timed in the build container on one thread and the same 10 s signal by tools/time_reference.js, like
+                # for like (both in Node's main context with the real globals; the ratio inside a `vm` sandbox is stored
+                # beside it)
                 rf = os.path.join(ROOT, "profiles", "cpu_baseline_ratio.json")
                 if os.path.isfile(rf):
                     ratio = json.load(open(rf))
                     result["cpu_baseline"]["restatement_over_reference"] = ratio["restatement_over_reference"]
                     result["cpu_baseline"]["reference_equivalent"] = round(j["msamples_per_s"] / ratio["restatement_over_reference"], 2)
-                    result["cpu_baseline"]["ratio_measured"] = "%s, %s: reference %.2f, restatement %.2f Msamples/s" % (
+                    result["cpu_baseline"]["ratio_measured"] = "%s, %s, both in the main context: reference %.2f, restatement %.2f Msamples/s" % (
                         ratio["node"], ratio["signal"], ratio["reference_msamples_per_s"], ratio["restatement_msamples_per_s"])
+                    if "vm_sandbox" in ratio:
+                        result["cpu_baseline"]["restatement_over_reference_in_vm_sandbox"] = ratio["vm_sandbox"]["restatement_over_reference"]
 
     if world > 1:
         dist.barrier()

@@ -39,7 +39,8 @@ typedef enum sono_status {
   SONO_ERR_CAPACITY = -5,  /* output buffer too small                                  */
   SONO_ERR_DEVICE = -6,    /* HIP runtime error, text in sono_last_error               */
   SONO_ERR_NO_DEVICE = -7, /* no usable GPU                                            */
-  SONO_ERR_FORMAT = -8     /* malformed RIFF/WAVE data (where the reference's DataView read throws) */
+  SONO_ERR_FORMAT = -8,    /* malformed RIFF/WAVE data (where the reference's DataView read throws) */
+  SONO_ERR_BUSY = -9       /* sono_stft_static: the GPU's static index plane is still in use by another stream */
 } sono_status;
 
 /* Window functions in the order of the plugin's switch, spectrogram.esm.js:105-151. */
@@ -90,7 +91,8 @@ typedef enum sono_arith {
 typedef enum sono_out_kind {
   SONO_OUT_U8_INDEX = 0, /* [frame][bin] uint8, bin 0 = DC (getFrequencies layout)               */
   SONO_OUT_RGBA8 = 1,    /* [row][column] RGBA8, row 0 = highest bin, column = frame
-                            (ImageData layout of the worker and of drawSpectrogram)              */
+                            (ImageData layout of the worker and of drawSpectrogram); the image must
+                            start on a 4-byte boundary (SONO_ERR_ARG otherwise)                   */
   SONO_OUT_F32_DB = 2,   /* [frame][bin] float32 20*log10(m), m = |X| (worker) or 2/N*|X| (plugin) */
   SONO_OUT_F32_MAG = 3,  /* [frame][bin] float32 m                                               */
   SONO_OUT_FEATURES = 4  /* [frame] sono_frame_feature: spectral peak of each frame over the kept band */
@@ -365,7 +367,9 @@ int sono_reserve(sono_ctx* ctx, uint64_t n_samples);
  * object: every GPU the library runs on holds one copy until the process ends.  A call whose frames x bins exceed
  * that size returns SONO_ERR_CAPACITY (32 MiB = 65 536 frames of 512 bins, i.e. 43 s at 384 kHz, FFT 1024,
  * hop 256; the reference loads files of at most 20 s, fileLoader.js:181).  Calls on the same GPU share the
- * array, whichever context or stream they use: two such calls must not overlap in time.  Same result as
+ * array, whichever context or stream they use: two such calls must not overlap in time.  Calls on one stream follow
+ * each other by construction; a call that arrives on another stream while the kernels of the array's last user are
+ * still running returns SONO_ERR_BUSY and enqueues nothing (checked with an event, not a wait).  Same result as
  * sono_stft_async, enqueued on the context's stream without waiting, no hipMalloc / hipFree inside. */
 #define SONO_STATIC_SCRATCH_BYTES (32u << 20)
 int sono_stft_static(sono_ctx* ctx, const void* pcm_dev, uint64_t n_samples, void* out_dev, uint64_t out_capacity_bytes);

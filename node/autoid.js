@@ -82,6 +82,7 @@ class RuleTable {
       const hFirst = harmonics.length, hCount = rule.harmonic ? rule.harmonic.length : 0;
       if (rule.harmonic) harmonics.push(...rule.harmonic.map((h) => h | 0));
       const cFirst = conds.length / 4;
+      if (rule.harmonic && rule.harmonic.length === 0) conds.push(0, 2, 0, 0);  // `[].includes(x)` is false: the rule never matches
       FIELDS.forEach((name, fi) => {
         const r = rule[name];
         if (!r) return;

@@ -155,6 +155,16 @@ for (const c of cases('worker_tables')) {
      m({ callType: 'FM', cfStart: 65 }) === 'No species matched' && m({ duration: 150 }) === 'two' &&
      m({ bandwidth: 9 }) === 'No species matched' && m({ lowestFreq: 10 }) === 'two' && m({}) === 'No species matched',
      'matcher: lists of ranges, relations, call types, harmonics, null bounds');
+  // an empty array is truthy in JavaScript: `harmonic: []` and `duration: []` never match (autoid_HK.js:229-231,211-212)
+  const empty = [
+    { name: 'no-harmonic', rules: [{ harmonic: [], duration: [1, 9] }] },
+    { name: 'no-range', rules: [{ duration: [] }] },
+    { name: 'falsy', rules: [{ duration: 0, bandwidth: null, callType: '', lowestFreq: [10, 20] }] },
+  ];
+  const e = (x) => autoIdHK(x, empty);
+  ok(e({ duration: 5, harmonic: 0 }) === 'No species matched' && e({ duration: 5 }) === 'No species matched' &&
+     e({ lowestFreq: 15 }) === 'falsy' && e({ lowestFreq: 15, duration: 1e9, bandwidth: -3 }) === 'falsy',
+     'matcher: empty arrays are truthy and never match; 0 / null / "" leave a field unconstrained');
 }
 
 // ---------------------------------------------------------------- GPU

@@ -15,6 +15,7 @@ LIB_PATH = os.path.join(_HERE, "libsonospec.so")
 OK = 0
 ERR_ARG, ERR_WINDOW, ERR_FFT_SIZE, ERR_COLORMAP, ERR_CAPACITY, ERR_DEVICE, ERR_NO_DEVICE = -1, -2, -3, -4, -5, -6, -7
 ERR_FORMAT = -8
+ERR_BUSY = -9
 WINDOW_IDS = {
     "bartlett": 0, "bartlettHann": 1, "blackman": 2, "cosine": 3, "gauss": 4,
     "hamming": 5, "hann": 6, "lanczoz": 7, "rectangular": 8, "triangular": 9,

@@ -64,6 +64,18 @@ def call_to_autoid_data(call, fft_n, hop, sample_rate, call_type=None, harmonic=
     return data
 
 
+def _js_truthy(v):
+    """JavaScript truthiness of a rule entry: an empty array is truthy (autoid_HK.js:229-231 test `rule.harmonic &&` and
+    `!rule[f]`), null / undefined / false / 0 / NaN / "" are not."""
+    if v is None or v is False:
+        return False
+    if isinstance(v, (int, float)) and not isinstance(v, bool):
+        return v == v and v != 0
+    if isinstance(v, str):
+        return v != ""
+    return True
+
+
 def _num(v):
     """A JavaScript value in a numeric comparison: null -> 0, undefined / non-numbers -> NaN."""
     if v is None:
@@ -91,13 +103,19 @@ class RuleTable:
                             self.call_types.append(t)
                         mask |= 1 << self.call_types.index(t)
                 h_first, h_count = len(harmonics), 0
-                if rule.get("harmonic"):                                   # :229
+                c_first = len(conds)
+                if _js_truthy(rule.get("harmonic")):                       # :229
                     harmonics.extend(int(h) for h in rule["harmonic"])
                     h_count = len(rule["harmonic"])
-                c_first = len(conds)
+                    if h_count == 0:   # `[].includes(x)` is false for every x: such a rule never matches
+                        conds.append((0, 2, 0, 0))
                 for fi, name in enumerate(FIELDS):                         # :230-259
                     r = rule.get(name)
-                    if not r:
+                    if not _js_truthy(r):
+                        continue
+                    if not isinstance(r, (list, tuple)) or len(r) == 0:
+                        # an empty array (or a truthy non-array): `val >= undefined` is false for every value
+                        conds.append((fi, 2, 0, 0))
                         continue
                     if isinstance(r[0], str) and len(r) == 1:
                         m = _REL.match(r[0])

@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -63,22 +64,36 @@ struct sono_ctx {
 // needs no allocation.  Host code never uses the array's name as an address; the per-device address comes from
 // hipGetSymbolAddress (static_scratch_of).
 static __device__ __align__(256) unsigned char scratch[SONO_STATIC_SCRATCH_BYTES];
-static void* g_scratch_ptr[64];       // per device, resolved with that device current
-static bool g_scratch_tried[64];
+// Per device: the array's address there (resolved once, with that device current, by whichever thread creates the
+// first context on it) and who used the array last -- an event recorded behind that call's kernels and the stream they
+// went to -- so that a call arriving on another stream while they still run is refused instead of corrupting them.
+struct StaticScratch {
+  std::once_flag once;
+  void* ptr = nullptr;
+  hipEvent_t done = nullptr;
+  hipStream_t last = nullptr;
+  bool used = false;
+};
+static StaticScratch g_static[64];
+static std::mutex g_static_mu;  // guards `last` / `used` and the record / query pair of sono_stft_static
 
 // Device address of `scratch` on the current device `dev`, or nullptr.  Called from sono_create.
 static void* static_scratch_of(int dev) {
   if (dev < 0 || dev >= 64) return nullptr;
-  if (!g_scratch_tried[dev]) {
+  StaticScratch& st = g_static[dev];
+  std::call_once(st.once, [&st] {
     void* ptr = nullptr;
     if (hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch)) != hipSuccess) {
       (void)hipGetLastError();
       ptr = nullptr;
     }
-    g_scratch_ptr[dev] = ptr;
-    g_scratch_tried[dev] = true;
-  }
-  return g_scratch_ptr[dev];
+    if (ptr && hipEventCreateWithFlags(&st.done, hipEventDisableTiming) != hipSuccess) {
+      (void)hipGetLastError();
+      st.done = nullptr;
+    }
+    st.ptr = ptr;
+  });
+  return st.ptr;
 }
 
 static thread_local const char* t_kernel = "";
@@ -555,9 +570,13 @@ static int launch_range(sono_ctx* c, const StftParams& q_in, const IndexScratch&
     if (r == 1) r = launch_stft_fast512(qq, c->stream);
     if (r == 1) r = launch_stft_fast2048(qq, c->stream);
     if (r == 1) r = launch_stft_fast4096(qq, c->stream);
-    if (r != SONO_OK) return fail(c, r, "kernel launch failed: %s", hipGetErrorString(hipGetLastError()));
-    note_route(c, ":rgba");
-    return SONO_OK;
+    if (r < 0) return fail(c, r, "kernel launch failed: %s", hipGetErrorString(hipGetLastError()));
+    if (r == SONO_OK) {
+      note_route(c, ":rgba");
+      return SONO_OK;
+    }
+    // (r == 1: no image writer took the call after all, e.g. an output pointer that is not 4-byte aligned; the
+    // two-kernel route below serves it)
   }
   if (rgba && q.row_of_bin0 == (int32_t)q.bin_hi - 1 && (q.nframes >= 16 || aux.single_chunk)) {
     // RGBA in two kernels: colour indices of a chunk of frames go to a [frame][bin] buffer small enough to stay in
@@ -771,6 +790,8 @@ static int transform(sono_ctx* c, const void* pcm, uint64_t L, void* out, uint64
   c->route.clear();
   const uint32_t n = c->cfg.fft_n, H = n / 2;
   const bool rgba = c->cfg.out_kind == SONO_OUT_RGBA8;
+  // every image route stores whole pixels (ImageData's Uint8ClampedArray sits on an ArrayBuffer, which is aligned)
+  if (rgba && (reinterpret_cast<uintptr_t>(out) & 3)) return fail(c, SONO_ERR_ARG, "an RGBA8 image must start on a 4-byte boundary");
   if (rgba && g.frames < g.width)  // L < N under the worker rule: a one-column, all-zero image (createImageData)
     HIP_TRY(c, hipMemsetAsync(out, 0, need, c->stream));
   if (g.frames == 0) return SONO_OK;
@@ -855,10 +876,30 @@ int sono_stft_async(sono_ctx* c, const void* pcm, uint64_t L, void* out, uint64_
 int sono_stft_static(sono_ctx* c, const void* pcm, uint64_t L, void* out, uint64_t cap) {
   if (!c) return SONO_ERR_ARG;
   if (c->cfg.out_kind != SONO_OUT_RGBA8) return fail(c, SONO_ERR_ARG, "sono_stft_static serves SONO_OUT_RGBA8 contexts");
-  void* sp = (c->device >= 0 && c->device < 64) ? g_scratch_ptr[c->device] : nullptr;
-  if (!sp) return fail(c, SONO_ERR_DEVICE, "the static index plane has no address on device %d", c->device);
-  const IndexScratch aux = {sp, (uint64_t)SONO_STATIC_SCRATCH_BYTES, true};
-  return transform(c, pcm, L, out, cap, aux, false);
+  if (c->device < 0 || c->device >= 64) return fail(c, SONO_ERR_DEVICE, "the static index plane has no address on device %d", c->device);
+  StaticScratch& st = g_static[c->device];
+  if (!st.ptr) return fail(c, SONO_ERR_DEVICE, "the static index plane has no address on device %d", c->device);
+  // Calls on one stream follow each other there; a call on another stream may only start once the kernels of the
+  // array's last user have finished.  (hipEventQuery and hipEventRecord allocate nothing.)
+  std::lock_guard<std::mutex> lock(g_static_mu);
+  HIP_TRY(c, hipSetDevice(c->device));
+  if (st.used && st.done && st.last != c->stream) {
+    const hipError_t q = hipEventQuery(st.done);
+    if (q == hipErrorNotReady)
+      return fail(c, SONO_ERR_BUSY, "the static index plane of device %d is in use by a call on another stream", c->device);
+    if (q != hipSuccess) (void)hipGetLastError();  // (e.g. a query that stream capture does not allow: the caller orders the calls)
+  }
+  const IndexScratch aux = {st.ptr, (uint64_t)SONO_STATIC_SCRATCH_BYTES, true};
+  const int rc = transform(c, pcm, L, out, cap, aux, false);
+  if (st.done) {
+    if (hipEventRecord(st.done, c->stream) == hipSuccess) {
+      st.last = c->stream;
+      st.used = true;
+    } else {
+      (void)hipGetLastError();
+    }
+  }
+  return rc;
 }
 
 const char* sono_kernel_route(const sono_ctx* c) { return c ? c->route.c_str() : ""; }

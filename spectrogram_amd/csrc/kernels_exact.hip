@@ -247,8 +247,11 @@ __global__ __launch_bounds__(kWaves * 64) void stft1024_exact_kernel(StftParams 
       process(list[e + ((h && two) ? 1 : 0)], h == 0 || two);
     }
     if (q[kQueueCount] > p.fixup) {
-      // more marked records than the list holds: the rest are found by scanning the records themselves (the
-      // listed ones are clean by now), one block of 64 records per wavefront at a time
+      // more marked records than the list holds: the rest are found by scanning the records themselves, one block of
+      // 64 records per wavefront at a time.  Nothing orders this scan behind the list pass of the OTHER workgroups, so it
+      // may still see the mark on a listed record that one of them is recomputing and recompute it as well: the same
+      // arithmetic on the same samples, i.e. the same 8 bytes stored twice -- duplicated work in the overflow case
+      // only, never a different result
       const sono_frame_feature* marks = reinterpret_cast<const sono_frame_feature*>(p.out) + p.col0;
       for (uint64_t blk = (uint64_t)blockIdx.x * kWaves + wave; blk * 64 < p.nframes; blk += (uint64_t)gridDim.x * kWaves) {
         const uint64_t fl = blk * 64 + lane;

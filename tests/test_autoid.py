@@ -130,3 +130,15 @@ def test_matcher_semantics_beyond_the_reference_table():
     assert m({"bandwidth": 9}) == "No species matched"          # [3, null]: val <= null is val <= 0
     assert m({"lowestFreq": 10}) == "two" and m({"lowestFreq": -1}) == "No species matched"           # [null, 20]: 0 <= val <= 20
     assert m({}) == "No species matched"
+    # JavaScript truthiness: an empty array is truthy, so `harmonic: []` makes `[].includes(x)` false for every x and
+    # `duration: []` compares against undefined bounds -- such rules never match (autoid_HK.js:229-231,211-212); a 0, a
+    # null or an empty string in their place is falsy and leaves the field unconstrained
+    empty = [
+        {"name": "no-harmonic", "rules": [{"harmonic": [], "duration": [1, 9]}]},
+        {"name": "no-range", "rules": [{"duration": []}]},
+        {"name": "falsy", "rules": [{"duration": 0, "bandwidth": None, "callType": "", "lowestFreq": [10, 20]}]},
+    ]
+    e = lambda d: auto_id_hk(d, empty)
+    assert e({"duration": 5, "harmonic": 0}) == "No species matched"
+    assert e({"duration": 5}) == "No species matched"
+    assert e({"lowestFreq": 15}) == "falsy" and e({"lowestFreq": 15, "duration": 1e9, "bandwidth": -3}) == "falsy"
