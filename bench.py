@@ -296,9 +296,9 @@ def main():
             },
             "checksum": checksum,
             "notes": "host of this line: Python ctypes over the C ABI (the same C entry points the Node addon calls; "
-                     "variants.node_host_* is the same workload through node/bench.js); colour indices within 1 LSB and float32 dB "
-                     "within 0.01 dB of the reference are asserted for bins within 90 dB of the frame peak (tests/); feature "
-                     "records are bit-exact",
+                     "variants.node_host_* is the same workload through node/bench.js); colour indices within 1 LSB of the reference; "
+                     "float32 dB within 0.01 dB for bins within 80 dB of the frame peak and within 0.04 dB (measured 0.026) for the "
+                     "rest of the display range down to the -100 dB floor (tests/); feature records are bit-exact",
         }
         if files_res:
             result["files"] = files_res

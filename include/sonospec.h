@@ -80,10 +80,17 @@ typedef enum sono_twiddle_mode {
 } sono_twiddle_mode;
 
 typedef enum sono_arith {
-  SONO_ARITH_FAST_F32 = 0, /* float32 kernels; dB within 0.01 dB, indices within 1 LSB.  Holds while the
-                              plugin quantiser's floor -gain_db-range_db is no lower than -100 dB (the
+  SONO_ARITH_FAST_F32 = 0, /* float32 kernels; colour indices within 1 LSB of the reference.  Holds while
+                              the plugin quantiser's floor -gain_db-range_db is no lower than -100 dB (the
                               reference's defaults 20 / 80 are); a context created with a lower floor
-                              computes colour indices and images in the exact arithmetic instead      */
+                              computes colour indices and images in the exact arithmetic instead.
+                              SONO_OUT_F32_DB: within 0.01 dB of the reference's own arithmetic for every
+                              bin above that floor that lies within 80 dB of its frame's largest bin, and
+                              within 0.04 dB for the bins 80..95 dB below it (measured worst case 0.026 dB
+                              at 512..4096 points under a full-scale tone: float32 rounding is about
+                              2e-7 of a transform's largest value, which is 0.3 % of a bin 94 dB down --
+                              a tenth of one colour index step).  Callers that need 0.01 dB all the way
+                              down take SONO_ARITH_EXACT_F64, which is bit-identical                    */
   SONO_ARITH_EXACT_F64 = 1 /* the reference's radix-2 dataflow in double with a float32 rounding
                               at every store, no FMA: magnitudes bit-identical to the JavaScript */
 } sono_arith;

@@ -86,8 +86,14 @@ function createBridge({ capacityBytes, maxUploadBytes = 1 << 30, maxPlugins = 32
         const rec = recordings.get(parts[1]);
         if (!rec) return json(res, 404, { error: 'unknown recording' });
         const q = url.searchParams;
-        const width = num(q, 'width', 300), x0 = num(q, 'x0', 0), ncols = num(q, 'ncols', width - x0);
-        const t = cache.tile(parts[1], pluginFor(q), rec, width, x0, ncols, num(q, 'channel', 0));
+        const width = num(q, 'width', 300), x0 = num(q, 'x0', 0), ncols = num(q, 'ncols', width - x0), channel = num(q, 'channel', 0);
+        // (what reaches the addon sizes device buffers: whole numbers inside the canvas, a canvas of a sane size)
+        const whole = (v, lo, hi) => Number.isInteger(v) && v >= lo && v <= hi;
+        if (!whole(width, 1, 1 << 24) || !whole(x0, 0, width) || !whole(ncols, 0, width - x0) || !whole(channel, 0, rec.numberOfChannels - 1) ||
+            !whole(num(q, 'height', 800), 1, 16384))
+          return json(res, 400, { error: 'width, x0, ncols, height, channel: whole numbers with 1 <= width <= 2^24, 0 <= x0, x0 + ncols <= width, ' +
+                                         '1 <= height <= 16384, channel < ' + rec.numberOfChannels });
+        const t = cache.tile(parts[1], pluginFor(q), rec, width, x0, ncols, channel);
         res.writeHead(200, { 'Content-Type': 'application/octet-stream', 'X-Width': String(t.width), 'X-Height': String(t.height),
                              'X-Cache-Hits': String(cache.hits), 'X-Cache-Misses': String(cache.misses) });
         return res.end(Buffer.from(t.data.buffer, t.data.byteOffset, t.data.byteLength));

@@ -80,7 +80,9 @@ class Spectrogram {
       for (let ch = 0; ch < 4; ch++) cm[4 * i + ch] = cc[ch];
     }
     this._colorMapUint = N.pluginLut(cm);                               // :262-271
-    this._engines = new Map();
+    this._engines = new Map();               // GPU contexts, least recently used first
+    this._maxEngines = t.maxEngines || 8;    // (automatic overlap makes one per distinct hop, i.e. per zoom step)
+    this._evictHooks = new Set();            // called with a context's handle before it is destroyed (tile caches)
     this.buffer = null;
   }
 
@@ -89,7 +91,16 @@ class Spectrogram {
     const fbRate = this.scale !== 'linear' && sampleRate ? sampleRate : 0;
     const key = [this.fftSamples, hop, this.windowFunc, this.alpha, this.gainDB, this.rangeDB, this.arith, this.scale, fbRate].join(':');
     let h = this._engines.get(key);
-    if (!h) {
+    if (h) {
+      this._engines.delete(key);            // most recently used last
+      this._engines.set(key, h);
+    } else {
+      while (this._engines.size >= this._maxEngines) {
+        const [oldKey, old] = this._engines.entries().next().value;
+        this._engines.delete(oldKey);
+        for (const hook of this._evictHooks) hook(old);   // device memory that lives on the context goes first
+        N.destroy(old);
+      }
       const n = this.fftSamples;
       const p = Math.floor(Math.log(n) / Math.LN2);
       if (Math.pow(2, p) !== n) throw 'Invalid buffer size, must be a power of 2.';   // :168-169

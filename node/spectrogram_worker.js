@@ -18,7 +18,8 @@ function makeWorkerCore(post, coreOptions) {
   let canvas = null, sampleRate = 44100;                               // spectrogramWorker.js:1
   let currentOptions = { colorMap: null, windowFunc: 'hann', gainDB: 20, rangeDB: 80 };   // :10-15
   let lut = null;                                                      // colorMapUint, :8
-  const engines = new Map();
+  const engines = new Map();                                           // GPU contexts, least recently used first
+  const maxEngines = (coreOptions && coreOptions.maxEngines) || 8;     // (a gain slider in 'plugin' scale makes one per step)
   const arith = (coreOptions && coreOptions.arith) || 'fast';
   const device = (coreOptions && coreOptions.device) || 0;
 
@@ -41,7 +42,15 @@ function makeWorkerCore(post, coreOptions) {
     const win = plugin ? S.windowId(opts.windowFunc) : S.WIN_WORKER_HANN;
     const key = fftSize + ':' + hop + (plugin ? ':p' + win + ':' + opts.alpha + ':' + gain + ':' + range : '');
     let h = engines.get(key);
-    if (!h) {
+    if (h) {
+      engines.delete(key);                  // most recently used last
+      engines.set(key, h);
+    } else {
+      while (engines.size >= maxEngines) {  // every context holds device tables and scratch: keep the most recent few
+        const [oldKey, old] = engines.entries().next().value;
+        engines.delete(oldKey);
+        N.destroy(old);
+      }
       const exact = arith === 'exact';
       h = N.create({
         fftN: fftSize, hop, windowId: win, alpha: plugin ? opts.alpha : undefined,

@@ -56,6 +56,15 @@ const buffer = { sampleRate: rate, length: n, numberOfChannels: 1, getChannelDat
   cache.drop();
   ok(cache.used === 0, 'drop releases');
   p.destroy(); q.destroy();
+  // a plugin keeps at most maxEngines contexts (automatic overlap makes one per distinct hop); a retired context takes
+  // its planes out of the cache first, and a tile of a retired configuration is simply computed again
+  const z = Spectrogram.create(Object.assign({}, opts, { noverlap: null, maxEngines: 3 }));
+  const first = cache.tile('z', z, buffer, 400).data.slice();
+  for (const w of [500, 650, 800, 1000, 1300]) cache.tile('z', z, buffer, w);
+  ok(z._engines.size <= 3, 'plugin contexts bounded: ' + z._engines.size);
+  ok(equal(cache.tile('z', z, buffer, 400).data, first), 'tile of a retired context, recomputed');
+  cache.drop();
+  z.destroy();
 }
 
 // over HTTP
@@ -96,6 +105,9 @@ server.listen(0, '127.0.0.1', async () => {
     ok(JSON.parse((await request('GET', '/stats')).body.toString()).misses === 1, 'colour map change keeps the plane');
     ok((await request('GET', '/tile/nope?width=10')).status === 404, 'unknown recording');
     ok((await request('GET', '/tile/bat1?width=10&x0=8&ncols=5')).status === 400, 'bad tile');
+    for (const bad of ['width=10.5', 'width=0', 'width=1e9', 'width=10&x0=-1', 'width=10&ncols=abc', 'width=10&height=0', 'width=10&height=1e6',
+                       'width=10&channel=3', 'width=NaN'])
+      ok((await request('GET', '/tile/bat1?' + bad)).status === 400, 'rejected before the addon: ' + bad);
     // the same option set (frequencyMax left at 0 = Nyquist) on recordings of two rates: each gets its own Nyquist
     const file2 = Buffer.from(file);
     file2.writeUInt32LE(rate / 2, 12 + 12); file2.writeUInt32LE(rate, 12 + 16);          // same samples declared at half the rate

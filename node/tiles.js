@@ -41,6 +41,8 @@ class TileCache {
       return pl;
     }
     this.misses++;
+    if (!this._hook) this._hook = (handle) => this.dropEngines([handle]);
+    if (plugin._evictHooks) plugin._evictHooks.add(this._hook);   // a context the plugin retires takes its planes with it
     const h = plugin._engine(hop, buffer.sampleRate);
     const x = buffer.getChannelData(channel);
     const g = N.geometry(h, x.length);

@@ -105,6 +105,12 @@ __global__ __launch_bounds__(kMaxWaves * 64, 4) void stft1024_u8_kernel(StftPara
   // blocks with equal blockIdx % 8 share an XCD (and its L2): give them neighbouring frame ranges
   const uint32_t per = gridDim.x >> 3;
   const uint32_t vb = (gridDim.x & 7) ? blockIdx.x : (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+  // A workgroup takes a CONTIGUOUS range of frames, `iters` iterations of its 16 wavefronts one after the other: the
+  // N - hop samples that neighbouring blocks of 64 frames share are then re-read from the workgroup's own cache lines
+  // an iteration later.  (Dealt out round-robin over the grid, every block's overlap with the next one was fetched
+  // again by another CU: 1.3 x the input bytes at hop = N/4.)
+  const uint64_t wg_iters_total = (npairs + 2 * kWaves - 1) / (2 * kWaves);
+  const uint64_t iters = (wg_iters_total + gridDim.x - 1) / gridDim.x;
 
   // Iteration `it` of this wavefront: unit = four consecutive frames (two per half-wavefront).  Frames (f0, f0+1) form
   // the complex input; st_a / st_b say which of the two results are stored.  An odd last frame is computed as the
@@ -115,8 +121,13 @@ __global__ __launch_bounds__(kMaxWaves * 64, 4) void stft1024_u8_kernel(StftPara
   };
   auto locate = [&](uint64_t it) -> Unit {
     Unit u;
+#ifdef SONO_EXP_INTERLEAVED
     const uint64_t pair0 = ((it * gridDim.x + vb) * kWaves + wave) * 2;
-    u.active = pair0 < npairs;  // wave-uniform
+    u.active = pair0 < npairs;
+#else
+    const uint64_t pair0 = (((uint64_t)vb * iters + it) * kWaves + wave) * 2;
+    u.active = it < iters && pair0 < npairs;  // wave-uniform
+#endif
     if (!u.active) {            // nothing left: point at frame 0 so that the sample loads stay in bounds
       u.f0 = 0;
       u.st_a = u.st_b = false;

@@ -350,8 +350,12 @@ __global__ __launch_bounds__(kWaves * 64) void stft2048_kernel(StftParams p, Fas
   const uint32_t per = gridDim.x >> 3;
   const uint32_t vb = (gridDim.x & 7) ? blockIdx.x : (blockIdx.x & 7) * per + (blockIdx.x >> 3);
   const uint64_t nunits = (p.nframes + 1) >> 1;  // a wavefront takes two consecutive frames
+  // a workgroup takes a contiguous range of frames (`iters` iterations of its wavefronts): the samples neighbouring
+  // blocks share are re-read from its own cache lines, not fetched again by another CU
+  const uint64_t iters = ((nunits + kWaves - 1) / kWaves + gridDim.x - 1) / gridDim.x;
+  const uint64_t unit_end = ((uint64_t)vb + 1) * iters * kWaves < nunits ? ((uint64_t)vb + 1) * iters * kWaves : nunits;
 
-  for (uint64_t unit = (uint64_t)vb * kWaves + wave; unit < nunits; unit += (uint64_t)gridDim.x * kWaves) {
+  for (uint64_t unit = (uint64_t)vb * iters * kWaves + wave; unit < unit_end; unit += kWaves) {
     const uint64_t f0 = unit * 2;
     // the frames transformed are fb, fb + 1; an odd last frame is the second of the pair before it (frames before f0
     // are another wavefront's and are not stored)

@@ -263,8 +263,12 @@ __global__ __launch_bounds__(kWaves * 64) void stft512_kernel(StftParams p, Fast
   const uint32_t per = gridDim.x >> 3;
   const uint32_t vb = (gridDim.x & 7) ? blockIdx.x : (blockIdx.x & 7) * per + (blockIdx.x >> 3);
   const uint64_t nunits = (p.nframes + 7) >> 3;  // a wavefront takes 8 consecutive frames, a half-wavefront 4 of them
+  // a workgroup takes a contiguous range of frames (`iters` iterations of its wavefronts): the samples neighbouring
+  // blocks share are re-read from its own cache lines, not fetched again by another CU
+  const uint64_t iters = ((nunits + kWaves - 1) / kWaves + gridDim.x - 1) / gridDim.x;
+  const uint64_t unit_end = ((uint64_t)vb + 1) * iters * kWaves < nunits ? ((uint64_t)vb + 1) * iters * kWaves : nunits;
 
-  for (uint64_t unit = (uint64_t)vb * kWaves + wave; unit < nunits; unit += (uint64_t)gridDim.x * kWaves) {
+  for (uint64_t unit = (uint64_t)vb * iters * kWaves + wave; unit < unit_end; unit += kWaves) {
     const uint64_t f0 = unit * 8 + 4 * h;  // this half-wavefront's frames are f0 .. f0+3
     // The four frames transformed are fb .. fb+3: A = (fb, fb+1), B = (fb+2, fb+3).  At the end of the recording the
     // block is shifted back so that every load stays in bounds; frames before f0 (another half-wavefront's) and

@@ -192,7 +192,9 @@ __global__ __launch_bounds__(kWaves * 64, 4) void stft1024_rgba_kernel(StftParam
     const Unit nxt = locate(it + 1);
     // iteration 1: every wavefront has read its quarters 2, 3 of the previous round (end of its iteration 0), so the slot
     // may be overwritten from here on
+#ifndef SONO_EXP_NOBARRIER
     if (sub == 1) __syncthreads();
+#endif
     // (the empty asm is a use of the sample registers: the wait for their loads lands here, before the image stores
     // of this iteration, and not behind them)
 #pragma unroll
@@ -311,7 +313,9 @@ __global__ __launch_bounds__(kWaves * 64, 4) void stft1024_rgba_kernel(StftParam
     } else {
       // the round's slot is complete once every wavefront is here; then take the first two quarters (after the last
       // round: of the empty round that only has the frames the last one left behind)
+#ifndef SONO_EXP_NOBARRIER
       __syncthreads();
+#endif
       if (round <= rounds) read_rows(fq, 0, round);
     }
   }

@@ -212,6 +212,43 @@ def test_plugin_magnitudes_exact_bitwise_and_fast_db(case):
         assert np.abs(db[vis] - 20 * np.log10(refd[vis])).max() <= 0.01
 
 
+@pytest.mark.parametrize("n", [512, 1024, 2048, 4096])
+def test_float32_db_bounds_down_to_the_display_floor(n):
+    """The whole 80 dB display range under the worst input float32 meets: a tone just under full scale (its peak sets the
+    transform's rounding noise, about 2e-7 of it) over a noise floor that fills the bins 60..95 dB below the peak, at
+    the reference's gain 20 / range 80 (floor -100 dB, spectrogram.esm.js:531-535).  Against the reference's own
+    arithmetic (the checker's float32 magnitudes): within 0.01 dB for every visible bin within 80 dB of its frame's
+    peak, within 0.04 dB for the visible bins 80..95 dB below it (measured worst case 0.026 dB), and the colour
+    indices within 1 LSB everywhere.  A full-scale frame has no visible bin further down: the floor is 94 dB below
+    the peak of a full-scale tone under a Hann window."""
+    hop = n // 4
+    rng = np.random.default_rng(n)
+    L = n + hop * 63 + 1
+    t = np.arange(L, dtype=np.float64)
+    seen_low = 0
+    for amp_noise in (3e-4, 1e-3, 3e-3):
+        x = (0.95 * np.sin(2 * np.pi * 0.1372 * t) + amp_noise * rng.uniform(-1, 1, L)).astype(np.float32)
+        ref_idx, mags, _, _ = oracle.plugin_get_frequencies(x, n, n - hop, want_mags=True)
+        with plugin_engine(n, hop, F.ARITH_FAST_F32, out_kind=F.OUT_F32_DB) as eng:
+            db = eng.stft(x)
+        with plugin_engine(n, hop, F.ARITH_FAST_F32) as eng:
+            idx = eng.stft(x)
+        refd = mags.astype(np.float64)
+        assert db.shape == refd.shape and idx.shape == ref_idx.shape
+        peak = refd.max(axis=1, keepdims=True)
+        below = 20 * np.log10(peak / np.maximum(refd, 1e-300))
+        err = np.abs(db - 20 * np.log10(np.maximum(refd, 1e-300)))
+        vis = refd > 10 ** (-100 / 20)
+        near, far = vis & (below < 80), vis & (below >= 80)
+        assert near.any() and err[near].max() <= 0.01, (n, amp_noise, err[near].max())
+        if far.any():
+            assert below[far].max() < 95 and err[far].max() <= 0.04, (n, amp_noise, below[far].max(), err[far].max())
+            seen_low += int(far.sum())
+        d = cyc_diff(idx, ref_idx)
+        assert d.max() <= 1 and (d != 0).mean() < 0.02, (n, amp_noise)
+    assert seen_low > 1000          # the zone is populated, not vacuously true
+
+
 def test_plugin_accurate_twiddles_differ_from_recurrence_at_4096():
     """The recurrence twiddles are part of the reference's result: at 4096 points they sit up to 3e-5
     away from the true roots of unity, which moves visible bins by more than the 0.01 dB tolerance, so
