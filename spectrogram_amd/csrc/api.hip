@@ -56,6 +56,12 @@ struct sono_ctx {
   bool pair_exact = false;  // StftParams::pair_exact
   double pair_asym = 0;     // StftParams::pair_asym
   bool pair_idx_ok = true;  // StftParams::pair_idx_ok
+  // Pairs of frames (1024 points) or a frame's even / odd samples (4096 points) under an asymmetric table: the kernels
+  // mark the loud units and a one-frame-per-transform launch recomputes those (StftParams::loud_flags)
+  bool loud_marks = false;
+  bool split_ok = true;     // StftParams::split_ok
+  float loud_thr_raw = 0.0f, loud_thr_win = 0.0f;
+  uint8_t* d_loud = nullptr;   // kLoudFlagBytes of marks
   std::string route;        // kernels of the most recent transform call (sono_kernel_route)
   std::string err;
 };
@@ -97,8 +103,13 @@ static void* static_scratch_of(int dev) {
 }
 
 static thread_local const char* t_kernel = "";
+static thread_local bool t_marks = false;
 namespace sono {
-void note_kernel(const char* name) { t_kernel = name; }
+void note_kernel(const char* name) {
+  t_kernel = name;
+  t_marks = false;
+}
+void note_marking(bool marks) { t_marks = marks; }
 }
 
 // Frames that the feature fix-up pass can list per launch (4 MiB; beyond it the pass scans for the rest).
@@ -323,7 +334,7 @@ void sono_destroy(sono_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
-  void* bufs[] = {c->d_window, c->d_tw, c->d_tw_exact, c->d_claim, c->d_lut, c->d_fast, c->d_in, c->d_out, c->d_aux, c->d_fb_bin, c->d_fb_w, c->d_fb_packed};
+  void* bufs[] = {c->d_window, c->d_tw, c->d_tw_exact, c->d_claim, c->d_lut, c->d_fast, c->d_in, c->d_out, c->d_aux, c->d_fb_bin, c->d_fb_w, c->d_fb_packed, c->d_loud};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
   if (c->ev_start) (void)hipEventDestroy(c->ev_start);
@@ -481,6 +492,10 @@ static bool compute_mw_ok(const sono_ctx* c, bool with_filterbank = false) {
   return true;
 }
 
+// Marks of the loud units: one byte per group of four frames, indexed modulo the buffer (16.7 M frames before two groups
+// share a byte, which only ever marks more).
+constexpr uint64_t kLoudFlagBytes = (uint64_t)1 << 22;
+
 // Default size of the RGBA index-chunk buffer when the context cannot write the image from the transform kernel.
 constexpr uint64_t kDefaultChunkBytes = (uint64_t)32 << 20;
 constexpr uint64_t kMaxChunkBytes = (uint64_t)96 << 20;
@@ -494,17 +509,58 @@ static int refresh_routes(sono_ctx* c) {
   c->fb_mw_ok = c->d_fb_bin ? compute_mw_ok(c, true) : false;
   c->pair_asym = table_asymmetry(c);
   c->pair_exact = c->pair_asym <= 5e-7;
-  {
-    // The largest |X| a frame of samples within +-1 can reach under this window is the sum of the window; its trace in
-    // the frame transformed with it is pair_asym times that.  Plugin scale: index 0 below r = 20 log10(2/N |X|) =
-    // -gain-range; worker scale: index 0 up to |X| = 1.  One decibel of margin.
-    double wsum = 0;
-    for (float w : c->h_window) wsum += std::fabs((double)w);
-    const double ghost = c->pair_asym * wsum;
-    const double floor_mag = c->cfg.scale_mode == SONO_SCALE_PLUGIN_DB
-                                 ? 0.5 * (double)c->cfg.fft_n * std::pow(10.0, -((double)c->cfg.gain_db + (double)c->cfg.range_db) / 20.0)
-                                 : 1.0;
-    c->pair_idx_ok = c->pair_exact || ghost <= floor_mag * std::pow(10.0, -1.0 / 20.0);
+  c->loud_marks = false;
+  c->split_ok = true;
+  if (c->pair_exact) {
+    c->pair_idx_ok = true;
+  } else {
+    // An asymmetric table (the plugin's recurrence factors, or a host table).  Two real frames transformed as one complex
+    // frame separate only up to the table's Hermitian defect: a bin is off by at most g times the largest sample of
+    // the pair (pair_defect_gains: the exact operator norm for this table, as the kernels hold it in float32, and this
+    // window).  A colour index moves by less than one step while |X| is off by less than eps = 10^(step in dB / 20) - 1
+    // of its value, and the smallest value that shows is the quantiser's floor; half of that is left to float32
+    // rounding.  So pairs are safe outright if full-scale samples cannot reach the bound; safe with the loud units
+    // marked and recomputed one frame per transform if a plausible level can (the kernels that mark: 1024 points, and
+    // the 4096-point kernel, which splits a frame into even and odd samples and carries the defect of the 2048-point
+    // transform inside it twice); otherwise such a context transforms one frame at a time from the start.
+    const uint32_t n = c->cfg.fft_n;
+    const bool plugin = c->cfg.scale_mode == SONO_SCALE_PLUGIN_DB;
+    const double eps = plugin ? std::pow(10.0, (double)c->cfg.range_db / (255.0 * 20.0)) - 1.0 : std::pow(10.0, 5.0 / 255.0) - 1.0;
+    const double floor_mag = plugin ? 0.5 * (double)n * std::pow(10.0, -((double)c->cfg.gain_db + (double)c->cfg.range_db) / 20.0) : 1.0;
+    const double crit = 0.5 * eps * floor_mag;
+    std::vector<double> tc(n), ts(n);
+    for (uint32_t i = 0; i + 1 < n; i++) {
+      tc[i] = (double)(float)c->h_cos[i];
+      ts[i] = (double)(float)c->h_sin[i];
+    }
+    double g_raw = 0, g_win = 0;
+    pair_defect_gains(n, tc.data(), ts.data(), c->h_window.data(), &g_raw, &g_win);
+    double thr_raw = g_raw > 0 ? crit / g_raw : 1e30, thr_win = g_win > 0 ? crit / g_win : 1e30;
+    c->pair_idx_ok = thr_raw >= 1.0;
+    bool marks = !c->pair_idx_ok && n == 1024;
+    if (n == 4096) {  // the kernel that splits a frame: the inner transform's table is the first eleven stages of this one
+      std::vector<float> we(n / 2), wo(n / 2);
+      for (uint32_t i = 0; i < n / 2; i++) {
+        we[i] = c->h_window[2 * i];
+        wo[i] = c->h_window[2 * i + 1];
+      }
+      double ge = 0, go = 0, gw = 0, gw2 = 0;
+      pair_defect_gains(n / 2, tc.data(), ts.data(), we.data(), &ge, &gw);
+      pair_defect_gains(n / 2, tc.data(), ts.data(), wo.data(), &go, &gw2);
+      const double g2 = 2.0 * (ge > go ? ge : go);  // X[k] = E[k] + w O[k]: both halves' errors add
+      thr_raw = g2 > 0 ? crit / g2 : 1e30;
+      thr_win = gw > 0 ? crit / (2.0 * gw) : 1e30;
+      marks = thr_raw < 1.0;
+      c->split_ok = !marks;
+    }
+    const bool index_out = c->cfg.out_kind == SONO_OUT_U8_INDEX || c->cfg.out_kind == SONO_OUT_RGBA8;
+    if (marks && index_out && thr_raw >= 0.02 && !c->d_fb_bin && c->cfg.arith == SONO_ARITH_FAST_F32) {
+      c->loud_marks = true;
+      c->loud_thr_raw = (float)thr_raw;
+      c->loud_thr_win = (float)thr_win;
+      if (!c->d_loud) HIP_TRY(c, hipMalloc((void**)&c->d_loud, kLoudFlagBytes));
+    }
+    // (the 4096-point kernel without marks would be unsafe: see launch_range)
   }
   const bool ragged_u8 = c->cfg.out_kind == SONO_OUT_U8_INDEX && ((c->bin_lo | c->bin_hi) & 3u) && (c->fast_mode || c->mw_ok);
   const bool fb_route = (c->fb_fast_mode || c->fb_mw_ok) && (c->cfg.out_kind == SONO_OUT_RGBA8 || c->cfg.out_kind == SONO_OUT_U8_INDEX);
@@ -548,11 +604,48 @@ static int launch_range(sono_ctx* c, const StftParams& q_in, const IndexScratch&
   // (whole groups of four bins, as for the linear scale; the image goes through a chunk of indices, whose band is
   // rounded outwards); at 512 / 2048 / 4096 points the three-pass kernel does.  Ragged index bands, and 1024-point
   // tables whose pairs would leak, take the route through a plane of magnitudes further down.
-  const bool fb_1024 = q_in.n == 1024 && c->fb_fast_mode && c->pair_idx_ok;
+  const bool fb_1024 = q_in.n == 1024 && c->fb_fast_mode;  // (pairs that would leak: its one-frame-per-transform flavour)
   const bool fb_mw = q_in.n != 1024 && c->fb_mw_ok;  // (the three-pass kernel: 512 / 2048 / 4096 points, pairs or single frames)
   const bool fb_fused = q_in.fb_bin && !exact && c->d_fb_packed && (fb_1024 || fb_mw) &&
                         (rgba || (q_in.out_kind == SONO_OUT_U8_INDEX && !((q_in.bin_lo | q_in.bin_hi | q_in.out_bins | q_in.out_bin0) & 3u)));
   StftParams q = q_in;
+  // An asymmetric table whose pairs (1024 points) or split frames (4096 points) are safe only below a sample level: the
+  // kernels mark the loud units and a one-frame-per-transform launch recomputes them (refresh_routes).
+  const bool loud = c->loud_marks && c->d_loud && !exact && !q_in.fb_bin && q_in.nframes >= 16 &&
+                    (q_in.out_kind == SONO_OUT_U8_INDEX || rgba);
+  if (loud) {
+    q.loud_flags = c->d_loud;
+    q.loud_mask = (uint32_t)(kLoudFlagBytes - 1);
+    q.loud_thr_raw = c->loud_thr_raw;
+    q.loud_thr_win = c->loud_thr_win;
+    if (q.n == 1024) q.pair_idx_ok = 1;  // (4096 points: the pairing three-pass kernel stays off, the splitting kernel marks)
+  }
+  // clears the marks of a launch's frames before it, and recomputes the marked units behind it
+  auto clear_marks = [&](const StftParams& u) -> int {
+    if (!u.loud_flags) return SONO_OK;
+    const uint64_t g0 = u.frame0 >> 2, g1 = (u.frame0 + u.nframes + 3) >> 2;
+    if (g1 - g0 + 1 >= kLoudFlagBytes) {
+      HIP_TRY(c, hipMemsetAsync(u.loud_flags, 0, kLoudFlagBytes, c->stream));
+    } else {
+      const uint64_t a = g0 & (kLoudFlagBytes - 1), b = g1 & (kLoudFlagBytes - 1);
+      if (a <= b) {
+        HIP_TRY(c, hipMemsetAsync(u.loud_flags + a, 0, b - a + 1, c->stream));
+      } else {
+        HIP_TRY(c, hipMemsetAsync(u.loud_flags + a, 0, kLoudFlagBytes - a, c->stream));
+        HIP_TRY(c, hipMemsetAsync(u.loud_flags, 0, b + 1, c->stream));
+      }
+    }
+    return SONO_OK;
+  };
+  auto redo_marked = [&](const StftParams& u) -> int {
+    if (!u.loud_flags || !t_marks) return SONO_OK;  // (a kernel that transforms one frame at a time marks nothing)
+    StftParams s2 = u;
+    s2.loud_only = 1;
+    int r2 = s2.n == 1024 ? launch_stft_fast_loud(s2, c->stream) : launch_stft_mw(s2, c->stream);
+    if (r2 != SONO_OK) return fail(c, r2 < 0 ? r2 : SONO_ERR_DEVICE, "launch of the pass over the marked frames failed");
+    note_route(c);
+    return SONO_OK;
+  };
   if (fb_fused) {
     q.fast_mode = fb_1024 ? c->fb_fast_mode : 0;
     q.mw_ok = fb_mw ? 1u : 0u;
@@ -566,6 +659,7 @@ static int launch_range(sono_ctx* c, const StftParams& q_in, const IndexScratch&
     if (!c->d_aux || c->d_aux_bytes < fast_rgba_scratch_bytes())
       return fail(c, SONO_ERR_ARG, "the context's image scratch is missing (tables changed without sono_set_tables?)");
     qq.tile_scratch = c->d_aux;
+    if (int rc = clear_marks(qq)) return rc;
     r = launch_stft_fast(qq, c->stream);
     if (r == 1) r = launch_stft_fast512(qq, c->stream);
     if (r == 1) r = launch_stft_fast2048(qq, c->stream);
@@ -573,7 +667,7 @@ static int launch_range(sono_ctx* c, const StftParams& q_in, const IndexScratch&
     if (r < 0) return fail(c, r, "kernel launch failed: %s", hipGetErrorString(hipGetLastError()));
     if (r == SONO_OK) {
       note_route(c, ":rgba");
-      return SONO_OK;
+      return redo_marked(qq);
     }
     // (r == 1: no image writer took the call after all, e.g. an output pointer that is not 4-byte aligned; the
     // two-kernel route below serves it)
@@ -589,7 +683,7 @@ static int launch_range(sono_ctx* c, const StftParams& q_in, const IndexScratch&
     u.out_bins = u.bin_hi - u.bin_lo;
     u.out_bin0 = u.bin_lo;
     u.lut = nullptr;
-    const bool fast_u8 = exact ? exact1024_available(u) : (fast_u8_available(u) || mw_u8_available(u) || fast);
+    const bool fast_u8 = exact ? exact_available(u) : (fast_u8_available(u) || mw_u8_available(u) || fast);
     if (fast_u8 || aux.single_chunk) {
       const uint64_t nb = u.out_bins;
       if (!aux.ptr || aux.bytes < 64 * nb)
@@ -607,19 +701,24 @@ static int launch_range(sono_ctx* c, const StftParams& q_in, const IndexScratch&
         u.col0 = 0;
         u.out = aux.ptr;
         r = 1;
+        bool marking = false;
         if (exact) {
           r = launch_stft_exact(u, c->stream);
           if (r == 1) r = launch_stft_general(u, true, c->stream);
         } else if (u.nframes >= 16) {
+          if (int rc = clear_marks(u)) return rc;
           if (fast) r = launch_stft_fast(u, c->stream);
           if (r == 1 && fast) r = launch_stft_fast512(u, c->stream);
           if (r == 1 && fast) r = launch_stft_fast2048(u, c->stream);
           if (r == 1 && fast) r = launch_stft_fast4096(u, c->stream);
           if (r == 1 && u.mw_ok) r = launch_stft_mw(u, c->stream);
+          marking = r == SONO_OK;
         }
         if (r == 1) r = launch_stft_general(u, exact, c->stream);
         if (r != SONO_OK) return fail(c, r, "kernel launch failed: %s", hipGetErrorString(hipGetLastError()));
         note_route(c, ":u8");
+        if (marking)
+          if (int rc = redo_marked(u)) return rc;
         r = launch_colorize((const uint8_t*)aux.ptr, u.nframes, (uint32_t)nb, u.bin_hi - q.bin_hi, q.bin_hi - q.bin_lo, q.lut,
                             (uint8_t*)q.out, q.width, q.col0 + f, c->stream);
         if (r != SONO_OK) return fail(c, r, "colorize launch failed");
@@ -705,16 +804,21 @@ static int launch_range(sono_ctx* c, const StftParams& q_in, const IndexScratch&
       w.col0 = 0;
       w.out = aux.ptr;
       r = 1;
+      bool marking = false;
       if (w.nframes >= 16) {
+        if (int rc = clear_marks(w)) return rc;
         if (fast) r = launch_stft_fast(w, c->stream);
         if (r == 1 && fast) r = launch_stft_fast512(w, c->stream);
         if (r == 1 && fast) r = launch_stft_fast2048(w, c->stream);
         if (r == 1 && fast) r = launch_stft_fast4096(w, c->stream);
         if (r == 1 && w.mw_ok) r = launch_stft_mw(w, c->stream);
+        marking = r == SONO_OK;
       }
       if (r == 1) r = launch_stft_general(w, false, c->stream);
       if (r != SONO_OK) return fail(c, r, "kernel launch failed: %s", hipGetErrorString(hipGetLastError()));
       note_route(c, ":band");
+      if (marking)
+        if (int rc = redo_marked(w)) return rc;
       uint8_t* dst = reinterpret_cast<uint8_t*>(q.out) + (q.col0 + f) * q.out_bins + (q.bin_lo - q.out_bin0);
       HIP_TRY(c, hipMemcpy2DAsync(dst, q.out_bins, reinterpret_cast<const uint8_t*>(aux.ptr) + (q.bin_lo - w.bin_lo), nb,
                                   q.bin_hi - q.bin_lo, w.nframes, hipMemcpyDeviceToDevice, c->stream));
@@ -736,12 +840,15 @@ static int launch_range(sono_ctx* c, const StftParams& q_in, const IndexScratch&
       listed = true;
     }
   }
+  if (!exact)
+    if (int rc = clear_marks(fq)) return rc;
   if (fast) r = launch_stft_fast(fq, c->stream);
   if (r != SONO_OK) listed = false;
   if (r == 1 && fast) r = launch_stft_fast512(fq, c->stream);
   if (r == 1 && fast) r = launch_stft_fast2048(fq, c->stream);
   if (r == 1 && fast) r = launch_stft_fast4096(fq, c->stream);
   if (r == 1 && q.mw_ok) r = launch_stft_mw(fq, c->stream);
+  const bool marking = !exact && r == SONO_OK && fq.loud_flags != nullptr;
   if (exact) r = launch_stft_exact(q, c->stream);
   // Feature records are integers that segmentation and species rules branch on, so they are the reference's in
   // both arithmetics: a float32 kernel marks the frames it cannot decide (two top bins too close, peak too close
@@ -759,6 +866,8 @@ static int launch_range(sono_ctx* c, const StftParams& q_in, const IndexScratch&
   if (r == 1) r = launch_stft_general(q, exact, c->stream);
   if (r != SONO_OK) return fail(c, r, "kernel launch failed: %s", hipGetErrorString(hipGetLastError()));
   note_route(c);
+  if (marking)
+    if (int rc = redo_marked(fq)) return rc;
   if (feat_fast) {
     StftParams u = q;
     u.twiddles = c->d_tw_exact;
@@ -813,6 +922,7 @@ static int transform(sono_ctx* c, const void* pcm, uint64_t L, void* out, uint64
   p.pair_exact = c->pair_exact ? 1u : 0u;
   p.pair_asym = c->pair_asym;
   p.pair_idx_ok = c->pair_idx_ok ? 1u : 0u;
+  p.split_ok = c->split_ok ? 1u : 0u;
   p.fb_bin = c->d_fb_bin;
   p.fb_w0 = c->d_fb_w;
   p.fb_w1 = c->d_fb_w ? c->d_fb_w + n / 2 : nullptr;

@@ -121,6 +121,61 @@ int fill_twiddles(uint32_t mode, uint32_t n, double* c, double* s) {
   return SONO_ERR_ARG;
 }
 
+// How far the spectrum of a REAL frame, transformed by the radix-2 network with the twiddle table (c, s), can be from
+// Hermitian symmetry.  The float32 kernels transform two real frames a, b as one complex frame z = a + i b and take frame
+// a's bin k as (Z[k] + conj Z[N-k]) / 2, which is exact only if conj A[N-k] == A[k]; the plugin's recurrence factors are
+// not conjugate-symmetric, so A carries a defect alpha[k] = conj A[N-k] - A[k] and the separated spectrum is off by
+// (alpha[k] - i beta[k]) / 2.  alpha is linear in the samples: alpha[k] = sum_n H[k][n] x[n] w[n] with
+// H[k][n] = conj F[N-k][n] - F[k][n], F the network's matrix.  For samples bounded by m that gives
+// |alpha[k]| <= m * sum_n |H[k][n]| w[n]; g_raw is that row sum maximised over k (bound in terms of the largest raw
+// sample), g_win the same without the window (bound in terms of the largest windowed sample).  F's columns come from
+// unit impulses, whose support doubles per stage: 2N operations per column, N columns.
+void pair_defect_gains(uint32_t n, const double* c, const double* s, const float* window, double* g_raw, double* g_win) {
+  std::vector<double> fr(n), fi(n), acc_raw(n / 2, 0.0), acc_win(n / 2, 0.0);
+  uint32_t bits = 0;
+  while ((1u << bits) < n) ++bits;
+  for (uint32_t j = 0; j < n; ++j) {
+    uint32_t pos = 0;
+    for (uint32_t b = 0; b < bits; ++b) pos |= ((j >> b) & 1u) << (bits - 1 - b);
+    // the impulse's image after each stage lives in the block of 2T entries around `pos`
+    uint32_t lo = pos;  // first entry of the support
+    fr[pos] = 1.0;
+    fi[pos] = 0.0;
+    for (uint32_t T = 1; T < n; T <<= 1) {
+      const uint32_t blk = lo & ~(2 * T - 1);  // the support [lo, lo + T) lies in one half of this block
+      const bool upper = (lo & T) != 0;
+      for (uint32_t q = 0; q < T; ++q) {
+        if (!upper) {  // the a[k] side: out[k] = out[k + T] = v
+          fr[blk + T + q] = fr[blk + q];
+          fi[blk + T + q] = fi[blk + q];
+        } else {       // the a[k + T] side: out[k] = w v, out[k + T] = -w v
+          const double vr = fr[blk + T + q], vi = fi[blk + T + q];
+          const double tr = c[T - 1 + q] * vr - s[T - 1 + q] * vi, ti = c[T - 1 + q] * vi + s[T - 1 + q] * vr;
+          fr[blk + q] = tr;
+          fi[blk + q] = ti;
+          fr[blk + T + q] = -tr;
+          fi[blk + T + q] = -ti;
+        }
+      }
+      lo = blk;
+    }
+    const double wj = window ? std::fabs((double)window[j]) : 1.0;
+    for (uint32_t k = 1; k < n / 2; ++k) {
+      const double hr = fr[n - k] - fr[k], hi = -fi[n - k] - fi[k];
+      const double h = std::sqrt(hr * hr + hi * hi);
+      acc_raw[k] += h * wj;
+      acc_win[k] += h;
+    }
+  }
+  double a = 0, b = 0;
+  for (uint32_t k = 1; k < n / 2; ++k) {
+    if (acc_raw[k] > a) a = acc_raw[k];
+    if (acc_win[k] > b) b = acc_win[k];
+  }
+  *g_raw = a;
+  *g_win = b;
+}
+
 int compute_geometry(uint32_t n, uint32_t hop, uint32_t rule, uint32_t bin_lo, uint32_t bin_hi, uint64_t L,
                      sono_geometry* g) {
   if (!is_pow2(n) || n < 2) return SONO_ERR_FFT_SIZE;

@@ -1,19 +1,27 @@
-// Exact-arithmetic STFT for 1024-point frames, in registers.
+// Exact-arithmetic STFT for 512-, 1024-, 2048- and 4096-point frames, in registers.
 //
 // Same operation sequence as the general kernel's double flavour -- the radix-2 decimation-in-time
 // network of spectrogramWorker.js:206-253 / spectrogram.esm.js:166-193 with per-stage twiddle tables,
 // double butterflies over float32 storage, no FMA contraction -- so the results are bit-identical to it
 // and to the JavaScript.  Only the schedule differs: a butterfly's inputs and factor are fixed by the
-// network, not by who computes it, so the ten stages are run as two in-register passes of five stages
-// with one transpose through LDS in between, instead of ten LDS round trips with workgroup barriers.
+// network, not by who computes it, so the stages are run as two in-register passes with one transpose
+// through LDS in between, instead of one LDS round trip with a workgroup barrier per stage.
 //
-// One half-wavefront (32 lanes) per frame.  The working array A[0..1023] (bit-reversed input order):
-//   pass 1, stages T = 1..16 : lane l holds A[32l + r] in register r; the factor of a butterfly depends
-//                               on r only (tw[T-1 + (r mod T)]), wave-uniform, read as scalars;
-//   transpose                 : lane l holds A[32r + l] in register r;
-//   pass 2, stages T = 32..512: partner registers are T/32 apart; the factor tw[T-1 + 32*(r mod T/32) + l]
-//                               differs per lane and is read from a [31][32] double2 copy in LDS.
-// A[k] is then X[k] in natural order: lane l, register r < 16 holds bin 32r + l.
+// G lanes own a frame and hold R = N / G values each (N = 512: 32 x 16, 1024: 32 x 32, 2048: 64 x 32,
+// 4096: 64 x 64).  The working array A[0..N-1] (bit-reversed input order):
+//   pass 1, stages T = 1..R/2   : lane l holds A[R l + r] in register r; the factor of a butterfly depends
+//                                 on r only (tw[T-1 + (r mod T)]), wave-uniform, read as scalars;
+//   stage T = R (512 and 2048)  : the partners A[k], A[k + R] sit in the same register of lanes 2m and 2m + 1; each
+//                                 lane fetches the other's value (DPP), both evaluate the reference's product
+//                                 t = w A[k + R] in the same double operations, the even lane keeps A[k] + t and
+//                                 the odd one A[k] - t;
+//   transpose                   : lane l holds A[G r + l] in register r;
+//   pass 2, stages T = G..N/2   : partner registers are T/G apart; the factor tw[T-1 + G (r mod T/G) + l]
+//                                 differs per lane and is read from an [R-1][G] double2 copy in LDS.
+// A[k] is then X[k] in natural order: lane l, register r < R/2 holds bin G r + l.
+//
+// Colour indices come from the exact quantisers behind their float32 predictor (sono_device.h): the double
+// sqrt / log10 run only for the bins whose quantiser argument is within rounding of an integer.
 //
 // Compile with -ffp-contract=off.
 #include <hip/hip_runtime.h>
@@ -23,17 +31,33 @@
 #include "sono_launch.h"
 
 namespace sono {
-namespace exact1024 {
+namespace exactreg {
 
-constexpr int kWaves = 8;           // wavefronts per workgroup: 16 frames per iteration
-constexpr int kPlane = 32 * 33;     // floats of one transpose buffer (row stride 33: conflict-free both ways)
-constexpr int kTwBytes = 31 * 32 * 16;
-constexpr int kWinBytes = 1024 * 4;
-constexpr int kLdsBytes = kTwBytes + kWinBytes + kWaves * 2 * kPlane * 4;
-
-__host__ __device__ constexpr int brev5(int v) {
-  return ((v & 1) << 4) | ((v & 2) << 2) | (v & 4) | ((v & 8) >> 2) | ((v & 16) >> 4);
+__host__ __device__ constexpr int ilog2c(int v) { return v <= 1 ? 0 : 1 + ilog2c(v >> 1); }
+__host__ __device__ constexpr int brevc(int v, int bits) {
+  int r = 0;
+  for (int i = 0; i < bits; ++i) r |= ((v >> i) & 1) << (bits - 1 - i);
+  return r;
 }
+
+template <int N>
+struct Geo {
+  static constexpr int G = N >= 2048 ? 64 : 32;   // lanes per frame
+  static constexpr int R = N / G;                 // values per lane
+  static constexpr int kLogG = ilog2c(G), kLogR = ilog2c(R);
+  static constexpr bool kCross = G > R;           // one stage (T = R) pairs neighbouring lanes
+  static constexpr int kPadShift = R > 32 ? 6 : 5;  // plane cell of A[i]: i + (i >> kPadShift), conflict-free both ways
+  static constexpr int kPlane = N + (N >> kPadShift);
+  static constexpr int kWaves = N == 4096 ? 4 : 8;  // wavefronts per workgroup
+  static constexpr int kFramesPerWave = 64 / G;
+  static constexpr int kFramesPerWg = kWaves * kFramesPerWave;
+  static constexpr int kTwRows = R - 1;
+  static constexpr int kTwBytes = kTwRows * G * 16;
+  static constexpr int kWinBytes = N * 4;
+  static constexpr int kLdsBytes = kTwBytes + kWinBytes + kFramesPerWg * kPlane * 4;
+  static_assert(kLdsBytes <= 160 * 1024, "LDS budget");
+  __host__ __device__ static constexpr int cell(int i) { return i + (i >> kPadShift); }
+};
 
 // spectrogramWorker.js:233-252 / spectrogram.esm.js:181-191: t = w * A[M]; A[M] = A[k] - t; A[k] += t,
 // every product and sum a double, every store a float32.
@@ -99,83 +123,106 @@ __global__ __launch_bounds__(kCompactThreads) void feature_marks_compact_kernel(
     if (at + i < capacity) q[kQueueHeader + at + i] = s_list[i];
 }
 
-// FIXUP: `p.out` is a SONO_OUT_FEATURES output of a float32 kernel; only the records it marked (reserved[0] != 0)
-// are recomputed, each wavefront scanning blocks of 64 records and taking the marked frames two at a time.
-template <typename In, bool FIXUP>
-__global__ __launch_bounds__(kWaves * 64) void stft1024_exact_kernel(StftParams p) {
+// FIXUP (1024 points): `p.out` is a SONO_OUT_FEATURES output of a float32 kernel; only the records it marked
+// (reserved[0] != 0) are recomputed, each wavefront scanning blocks of 64 records and taking the marked frames two at a time.
+template <int N, typename In, bool FIXUP>
+__global__ __launch_bounds__(Geo<N>::kWaves * 64) void stft_exact_kernel(StftParams p) {
+  using X = Geo<N>;
+  constexpr int G = X::G, R = X::R, kWaves = X::kWaves;
+  static_assert(!FIXUP || N == 1024, "the fix-up pass is the 1024-point flavour");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  double2* tw_lds = reinterpret_cast<double2*>(smem);                 // [31][32]: row t-1+j of stage T = 32t
-  float* win_lds = reinterpret_cast<float*>(smem + kTwBytes);          // window[j]
+  double2* tw_lds = reinterpret_cast<double2*>(smem);                    // [R-1][G]: row t-1+j of stage T = G t
+  float* win_lds = reinterpret_cast<float*>(smem + X::kTwBytes);          // window[j]
   const double2* __restrict__ tw = reinterpret_cast<const double2*>(p.twiddles);
-  for (int i = threadIdx.x; i < 31 * 32; i += kWaves * 64) {
-    const int row = i >> 5, lane_p = i & 31;
+  for (int i = threadIdx.x; i < X::kTwRows * G; i += kWaves * 64) {
+    const int row = i / G, lane_p = i % G;
     const int t = 1 << (31 - __builtin_clz(row + 1)), j = row + 1 - t;
-    tw_lds[i] = tw[32 * t - 1 + 32 * j + lane_p];
+    tw_lds[i] = tw[G * t - 1 + G * j + lane_p];
   }
-  for (int i = threadIdx.x; i < 1024; i += kWaves * 64) win_lds[i] = p.window[i];
+  for (int i = threadIdx.x; i < N; i += kWaves * 64) win_lds[i] = p.window[i];
   __syncthreads();
 
-  const int lane = threadIdx.x & 63, l = lane & 31, h = lane >> 5;
+  const int lane = threadIdx.x & 63, l = lane & (G - 1), h = lane / G;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  float* plane = reinterpret_cast<float*>(smem + kTwBytes + kWinBytes) + (wave * 2 + h) * kPlane;
+  float* plane = reinterpret_cast<float*>(smem + X::kTwBytes + X::kWinBytes) + (wave * X::kFramesPerWave + h) * X::kPlane;
   const In* __restrict__ x = reinterpret_cast<const In*>(p.pcm);
-  const int lb = brev5(l);
-  const double two_over_n = 2.0 / 1024.0;
+  const int lb = (int)(__builtin_bitreverse32((uint32_t)l) >> (32 - X::kLogG));  // the lane's bits reversed
+  const double two_over_n = 2.0 / (double)N;
   const bool worker = p.scale_mode == SONO_SCALE_WORKER_LOG5;
+  const ExactPred pred = make_exact_pred(p.scale_mode, N, p.gain_db, p.range_db);
 
-  // one frame per half-wavefront: frame `fi` of the launch; a spare half (live == false) stores nothing
+  // one frame per group of G lanes: frame `fi` of the launch; a spare group (live == false) stores nothing
   auto process = [&](const uint64_t fi, const bool live) {
-    const uint64_t frame = p.frame0 + (live ? fi : p.nframes - 1);  // a spare half repeats the last frame and stores nothing
+    const uint64_t frame = p.frame0 + (live ? fi : p.nframes - 1);  // a spare group repeats the last frame and stores nothing
     const uint64_t a = frame * p.hop;
 
-    // A[32l + r] = float32(x[j] * w[j]) with j = bitreverse10(32l + r) = 32*brev5(r) + brev5(l)
-    float re[32], im[32];
+    // A[R l + r] = float32(x[j] * w[j]) with j = bitreverse(R l + r) = G * brev(r) + brev(l)
+    float re[R], im[R];
 #pragma unroll
-    for (int q = 0; q < 32; ++q) {
-      const int j = 32 * q + lb;
-      re[brev5(q)] = ld<In>(x, a + j) * win_lds[j];
-      im[brev5(q)] = 0.0f;
+    for (int q = 0; q < R; ++q) {
+      const int j = G * q + lb;
+      re[brevc(q, X::kLogR)] = ld<In>(x, a + j) * win_lds[j];
+      im[brevc(q, X::kLogR)] = 0.0f;
     }
-    // stages T = 1, 2, 4, 8, 16
+    // stages T = 1 .. R/2
 #pragma unroll
-    for (int T = 1; T < 32; T <<= 1) {
+    for (int T = 1; T < R; T <<= 1) {
 #pragma unroll
       for (int z = 0; z < T; ++z) {
         const double2 w = tw[T - 1 + z];  // wave-uniform
 #pragma unroll
-        for (int g = 0; g < 32; g += 2 * T) butterfly(re[g + z], im[g + z], re[g + z + T], im[g + z + T], w.x, w.y);
+        for (int g = 0; g < R; g += 2 * T) butterfly(re[g + z], im[g + z], re[g + z + T], im[g + z + T], w.x, w.y);
       }
     }
-    // transpose: lane l, register r  ->  lane r, register l (one plane after the other through one buffer)
+    if constexpr (X::kCross) {
+      // stage T = R: A[k] in the even lane, A[k + R] in the odd one, factor tw[R - 1 + r]
+      const bool odd = (l & 1) != 0;
 #pragma unroll
-    for (int r = 0; r < 32; ++r) plane[l * 33 + r] = re[r];
+      for (int r = 0; r < R; ++r) {
+        const double2 w = tw[R - 1 + r];  // wave-uniform
+        const float pr = dpp_f<kDppXor1>(re[r]), pi = dpp_f<kDppXor1>(im[r]);
+        const double oM = odd ? re[r] : pr, lM = odd ? im[r] : pi;
+        const double ok = odd ? pr : re[r], lk = odd ? pi : im[r];
+        const double m = w.x * oM - w.y * lM;
+        const double y = w.x * lM + w.y * oM;
+        const float dr = (float)(ok - m), di = (float)(lk - y);
+        const float sr = (float)(ok + m), si = (float)(lk + y);
+        re[r] = odd ? dr : sr;
+        im[r] = odd ? di : si;
+      }
+    }
+    // transpose: lane l, register r (A[R l + r])  ->  lane l, register r (A[G r + l]); one plane after the other
+#pragma unroll
+    for (int r = 0; r < R; ++r) plane[(R * l + r) + ((R * l + r) >> X::kPadShift)] = re[r];
     wave_sync();
 #pragma unroll
-    for (int r = 0; r < 32; ++r) re[r] = plane[r * 33 + l];
+    for (int r = 0; r < R; ++r) re[r] = plane[(G * r + l) + ((G * r + l) >> X::kPadShift)];
     wave_sync();
 #pragma unroll
-    for (int r = 0; r < 32; ++r) plane[l * 33 + r] = im[r];
+    for (int r = 0; r < R; ++r) plane[(R * l + r) + ((R * l + r) >> X::kPadShift)] = im[r];
     wave_sync();
 #pragma unroll
-    for (int r = 0; r < 32; ++r) im[r] = plane[r * 33 + l];
+    for (int r = 0; r < R; ++r) im[r] = plane[(G * r + l) + ((G * r + l) >> X::kPadShift)];
     wave_sync();
-    // stages T = 32t, t = 1, 2, 4, 8, 16
+    // stages T = G t, t = 1 .. R/2
 #pragma unroll
-    for (int t = 1; t < 32; t <<= 1) {
+    for (int t = 1; t < R; t <<= 1) {
 #pragma unroll
       for (int j = 0; j < t; ++j) {
-        const double2 w = tw_lds[(t - 1 + j) * 32 + l];
+        const double2 w = tw_lds[(t - 1 + j) * G + l];
 #pragma unroll
-        for (int g = 0; g < 32; g += 2 * t) butterfly(re[g + j], im[g + j], re[g + j + t], im[g + j + t], w.x, w.y);
+        for (int g = 0; g < R; g += 2 * t) butterfly(re[g + j], im[g + j], re[g + j + t], im[g + j + t], w.x, w.y);
       }
     }
 
-    // bins 32r + l, r < 16.  The quantisers are long (double sqrt and log10), so the bins are parked in
-    // the transpose buffer and taken one at a time by a rolled loop instead of 16 inlined copies.
+    // bins G r + l, r < R/2.  The exact quantisers are long where the predictor does not decide, so the bins are
+    // parked in the transpose buffer and taken one at a time by a rolled loop instead of R/2 inlined copies.
+    auto cell_re = [&](int r) { return (G * r + l) + ((G * r + l) >> X::kPadShift); };
+    auto cell_im = [&](int r) { return (G * (R / 2 + r) + l) + ((G * (R / 2 + r) + l) >> X::kPadShift); };
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      plane[r * 33 + l] = re[r];
-      plane[(16 + r) * 33 + l] = im[r];
+    for (int r = 0; r < R / 2; ++r) {
+      plane[cell_re(r)] = re[r];
+      plane[cell_im(r)] = im[r];
     }
     wave_sync();
     const uint64_t orow = (p.col0 + fi) * p.out_bins;
@@ -184,9 +231,9 @@ __global__ __launch_bounds__(kWaves * 64) void stft1024_exact_kernel(StftParams 
       float best_m = -1.0f, best_r = 0.0f, best_i = 0.0f;
       int best_k = (int)p.bin_lo;
 #pragma unroll 1
-      for (int r = 0; r < 16; ++r) {
-        const int y = 32 * r + l;
-        const float fr = plane[r * 33 + l], fi2 = plane[(16 + r) * 33 + l];
+      for (int r = 0; r < R / 2; ++r) {
+        const int y = G * r + l;
+        const float fr = plane[cell_re(r)], fi2 = plane[cell_im(r)];
         const double e = fr, s = fi2;
         const double mag = sqrt(e * e + s * s);
         const float m = worker ? (float)mag : (float)(two_over_n * mag);
@@ -195,7 +242,7 @@ __global__ __launch_bounds__(kWaves * 64) void stft1024_exact_kernel(StftParams 
         }
       }
 #pragma unroll
-      for (int msk = 1; msk < 32; msk <<= 1) {
+      for (int msk = 1; msk < G; msk <<= 1) {
         const float om = __shfl_xor(best_m, msk, 64), orr = __shfl_xor(best_r, msk, 64), oi = __shfl_xor(best_i, msk, 64);
         const int ok = __shfl_xor(best_k, msk, 64);
         if (om > best_m || (om == best_m && ok < best_k)) { best_m = om; best_k = ok; best_r = orr; best_i = oi; }
@@ -210,14 +257,14 @@ __global__ __launch_bounds__(kWaves * 64) void stft1024_exact_kernel(StftParams 
       }
     } else if (live) {
 #pragma unroll 4
-      for (int r = 0; r < 16; ++r) {
-        const int y = 32 * r + l;
+      for (int r = 0; r < R / 2; ++r) {
+        const int y = G * r + l;
         if (y < (int)p.bin_lo || y >= (int)p.bin_hi) continue;
-        const float fr = plane[r * 33 + l], fi2 = plane[(16 + r) * 33 + l];
+        const float fr = plane[cell_re(r)], fi2 = plane[cell_im(r)];
         const uint64_t o = orow + (uint32_t)(y - (int)p.out_bin0);
         if (p.out_kind == SONO_OUT_U8_INDEX) {
-          const uint32_t idx = worker ? worker_index_exact(fr, fi2)
-                                      : plugin_index_exact(plugin_mag_exact(fr, fi2, two_over_n), p.gain_db, p.range_db);
+          const uint32_t idx = worker ? worker_index_exact_p(fr, fi2, pred)
+                                      : plugin_index_exact_p(fr, fi2, two_over_n, p.gain_db, p.range_db, pred);
           reinterpret_cast<uint8_t*>(p.out)[o] = (uint8_t)idx;
         } else {
           const double e = fr, s = fi2;
@@ -244,7 +291,7 @@ __global__ __launch_bounds__(kWaves * 64) void stft1024_exact_kernel(StftParams 
     const uint32_t* list = q + kQueueHeader;
     for (uint64_t e = ((uint64_t)blockIdx.x * kWaves + wave) * 2; e < listed; e += (uint64_t)gridDim.x * kWaves * 2) {
       const bool two = e + 1 < listed;
-      process(list[e + ((h && two) ? 1 : 0)], h == 0 || two);
+      process(list[e + ((h && two) ? 1 : 0)], h == 0 || two);   // (1024 points: two frames per wavefront)
     }
     if (q[kQueueCount] > p.fixup) {
       // more marked records than the list holds: the rest are found by scanning the records themselves, one block of
@@ -269,39 +316,56 @@ __global__ __launch_bounds__(kWaves * 64) void stft1024_exact_kernel(StftParams 
       }
     }
   } else {
-    for (uint64_t base = (uint64_t)blockIdx.x * (kWaves * 2); base < p.nframes; base += (uint64_t)gridDim.x * (kWaves * 2)) {
-      const uint64_t fi = base + wave * 2 + h;
+    for (uint64_t base = (uint64_t)blockIdx.x * X::kFramesPerWg; base < p.nframes; base += (uint64_t)gridDim.x * X::kFramesPerWg) {
+      const uint64_t fi = base + wave * X::kFramesPerWave + h;
       process(fi, fi < p.nframes);
     }
   }
 }
 
-}  // namespace exact1024
+}  // namespace exactreg
 
-bool exact1024_available(const StftParams& p) {
-  return p.n == 1024 && p.twiddles && !p.fb_bin && p.nframes >= 16 &&
+bool exact_available(const StftParams& p) {
+#ifdef SONO_EXP_EXACT1024ONLY
+  if (p.n != 1024) return false;
+#endif
+  return (p.n == 512 || p.n == 1024 || p.n == 2048 || p.n == 4096) && p.twiddles && !p.fb_bin && p.nframes >= 16 &&
          (p.out_kind == SONO_OUT_U8_INDEX || p.out_kind == SONO_OUT_F32_DB || p.out_kind == SONO_OUT_F32_MAG ||
           p.out_kind == SONO_OUT_FEATURES);
 }
 
+namespace exactreg {
+template <int N>
+static int launch_n(const StftParams& p, hipStream_t stream) {
+  using X = Geo<N>;
+  const int cus = device_cu_count();
+  const uint64_t need = (p.nframes + X::kFramesPerWg - 1) / X::kFramesPerWg;
+  const uint64_t cap = (uint64_t)cus * (N == 512 ? 2 : 1);   // (512 points: two workgroups fit a CU)
+  const uint32_t grid = (uint32_t)(need < cap ? need : cap);
+  if (p.in_kind == SONO_IN_I16) {
+    auto kern = stft_exact_kernel<N, int16_t, false>;
+    SONO_GRANT_LDS(kern, X::kLdsBytes);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(X::kWaves * 64), X::kLdsBytes, stream, p);
+  } else {
+    auto kern = stft_exact_kernel<N, float, false>;
+    SONO_GRANT_LDS(kern, X::kLdsBytes);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(X::kWaves * 64), X::kLdsBytes, stream, p);
+  }
+  return hipGetLastError() == hipSuccess ? SONO_OK : SONO_ERR_DEVICE;
+}
+}  // namespace exactreg
+
 // Returns 1 if this launch is not served here (the caller falls back to the general kernel).
 int launch_stft_exact(const StftParams& p, void* stream_v) {
-  using namespace exact1024;
-  if (!exact1024_available(p)) return 1;
+  using namespace exactreg;
+  if (!exact_available(p)) return 1;
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_v);
-  const int cus = device_cu_count();
-  const uint64_t need = (p.nframes + kWaves * 2 - 1) / (kWaves * 2);
-  const uint32_t grid = (uint32_t)(need < (uint64_t)cus ? need : (uint64_t)cus);
-#define SONO_LAUNCH_X(In)                                                                                        \
-  do {                                                                                                           \
-    auto kern = stft1024_exact_kernel<In, false>;                                                                \
-    SONO_GRANT_LDS(kern, kLdsBytes);                                                                             \
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(kWaves * 64), kLdsBytes, stream, p);                               \
-  } while (0)
-  if (p.in_kind == SONO_IN_I16) SONO_LAUNCH_X(int16_t); else SONO_LAUNCH_X(float);
-#undef SONO_LAUNCH_X
-  note_kernel("stft1024_exact_kernel");
-  return hipGetLastError() == hipSuccess ? SONO_OK : SONO_ERR_DEVICE;
+  switch (p.n) {
+    case 512: note_kernel("stft512_exact_kernel"); return launch_n<512>(p, stream);
+    case 1024: note_kernel("stft1024_exact_kernel"); return launch_n<1024>(p, stream);
+    case 2048: note_kernel("stft2048_exact_kernel"); return launch_n<2048>(p, stream);
+    default: note_kernel("stft4096_exact_kernel"); return launch_n<4096>(p, stream);
+  }
 }
 
 // p.tile_scratch: the queue (kQueueHeader words + p.fixup list entries, p.fixup >= 1).
@@ -310,11 +374,14 @@ bool features_fixup_available(const StftParams& p) {
          p.fixup > 0 && p.nframes < ((uint64_t)1 << 32);   // frame numbers are 32-bit list entries
 }
 
-uint64_t features_fixup_queue_bytes(uint32_t capacity) { return ((uint64_t)exact1024::kQueueHeader + capacity) * 4; }
+uint64_t features_fixup_queue_bytes(uint32_t capacity) { return ((uint64_t)exactreg::kQueueHeader + capacity) * 4; }
 
 // `listed`: the float32 kernel has put the frames it marked into the queue itself (StftParams::feat_queue).
 int launch_features_fixup(const StftParams& p, void* stream_v, bool listed) {
-  using namespace exact1024;
+  using namespace exactreg;
+  using X = Geo<1024>;
+  constexpr int kWaves = X::kWaves;
+  constexpr int kLdsBytes = X::kLdsBytes;
   if (!features_fixup_available(p)) return 1;
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_v);
   if (!listed) {
@@ -330,7 +397,7 @@ int launch_features_fixup(const StftParams& p, void* stream_v, bool listed) {
   const uint32_t grid = (uint32_t)(need < cap ? need : cap);
 #define SONO_LAUNCH_F(In)                                                                                        \
   do {                                                                                                           \
-    auto kern = stft1024_exact_kernel<In, true>;                                                                 \
+    auto kern = stft_exact_kernel<1024, In, true>;                                                                 \
     SONO_GRANT_LDS(kern, kLdsBytes);                                                                             \
     hipLaunchKernelGGL(kern, dim3(grid), dim3(kWaves * 64), kLdsBytes, stream, p);                               \
   } while (0)

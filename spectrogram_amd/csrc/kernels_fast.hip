@@ -31,6 +31,7 @@
 #include "sono_fft32.h"
 #include "sono_internal.h"
 #include "sono_launch.h"
+#include "sono_loud.h"
 #include "sono_rgba_flush.h"
 
 namespace sono {
@@ -69,7 +70,6 @@ __global__ __launch_bounds__(kMaxWaves * 64, 4) void stft1024_u8_kernel(StftPara
                                                                         const float2* __restrict__ tw_table) {
   constexpr bool FEAT = OUT == kOutFeatures, FLT = OUT == kOutDb || OUT == kOutMag;
   constexpr bool SINGLE = HOP32 < 0, BANK = OUT == kOutU8Bank;
-  static_assert(!(SINGLE && BANK), "the filter bank comes with the paired flavour");
   static_assert(!(SINGLE && FEAT), "the feature records come from the paired flavour (its marks cover the cross-talk)");
   constexpr int kThreads = kMaxWaves * 64, kWaves = kMaxWaves;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -117,17 +117,14 @@ __global__ __launch_bounds__(kMaxWaves * 64, 4) void stft1024_u8_kernel(StftPara
   // second member of the pair before it.  `active` is false when the wavefront has no frame left.
   struct Unit {
     uint64_t f0;
+    uint64_t w0;  // the wavefront's first frame (wave-uniform)
     bool active, st_a, st_b;
   };
   auto locate = [&](uint64_t it) -> Unit {
     Unit u;
-#ifdef SONO_EXP_INTERLEAVED
-    const uint64_t pair0 = ((it * gridDim.x + vb) * kWaves + wave) * 2;
-    u.active = pair0 < npairs;
-#else
     const uint64_t pair0 = (((uint64_t)vb * iters + it) * kWaves + wave) * 2;
     u.active = it < iters && pair0 < npairs;  // wave-uniform
-#endif
+    u.w0 = SINGLE ? pair0 : 2 * pair0;
     if (!u.active) {            // nothing left: point at frame 0 so that the sample loads stay in bounds
       u.f0 = 0;
       u.st_a = u.st_b = false;
@@ -177,6 +174,17 @@ __global__ __launch_bounds__(kMaxWaves * 64, 4) void stft1024_u8_kernel(StftPara
     const Unit nxt = locate(it + 1);
     const uint64_t f0 = cur.f0;
     const bool st_a = cur.st_a, st_b = SINGLE ? false : cur.st_b;
+    if constexpr (SINGLE && OUT == kOutU8) {
+      // the second launch behind a kernel that pairs frames: only the units it marked (StftParams::loud_flags)
+      if (p.loud_only && !is_loud(p, p.frame0 + cur.w0, 2)) {  // wave-uniform
+        fetch(nxt);
+        cur = nxt;
+        continue;
+      }
+    }
+    if constexpr (TABLE && !SINGLE && (OUT == kOutU8)) {
+      if (p.loud_flags) mark_loud(p, max_abs(raw) > p.loud_thr_raw, p.frame0 + cur.w0, 4);
+    }
 
     float re[32], im[32];
     {
@@ -290,7 +298,7 @@ __global__ __launch_bounds__(kMaxWaves * 64, 4) void stft1024_u8_kernel(StftPara
         const float4 q23 = SINGLE ? make_float4(0, 0, 0, 0) : *reinterpret_cast<const float4*>(mbuf + idx + 2);
         uint32_t wa = 0, wb = 0;
         float fa[4] = {0, 0, 0, 0}, fb[4] = {0, 0, 0, 0};
-        const bool in_band = k >= (int)p.bin_lo && k < (int)p.bin_hi;
+        const bool in_band = k + 3 >= (int)p.bin_lo && k < (int)p.bin_hi;  // (an image's band may start or end inside a quad)
 #define SONO_BIN(B, ZR, ZI, PR, PI)                                          \
   {                                                                          \
     const float ar = SINGLE ? (ZR) : (ZR) + (PR), ai = SINGLE ? (ZI) : (ZI) - (PI); \
@@ -339,9 +347,13 @@ __global__ __launch_bounds__(kMaxWaves * 64, 4) void stft1024_u8_kernel(StftPara
             if (st_b) *reinterpret_cast<float4*>(o + row_b) = make_float4(fb[0], fb[1], fb[2], fb[3]);
           }
         } else if (!FEAT && !BANK && in_band) {
-          const uint32_t col = k - p.out_bin0;
-          if (st_a) *reinterpret_cast<uint32_t*>(out + row_a + col) = wa;
-          if (st_b) *reinterpret_cast<uint32_t*>(out + row_b + col) = wb;
+          if (SINGLE && p.out_kind == SONO_OUT_RGBA8) {  // the second launch behind an image writer: the frame's column
+            if (st_a) store_column_pixels(p, f0, k, wa);
+          } else {
+            const uint32_t col = k - p.out_bin0;
+            if (st_a) *reinterpret_cast<uint32_t*>(out + row_a + col) = wa;
+            if (st_b) *reinterpret_cast<uint32_t*>(out + row_b + col) = wb;
+          }
         }
       }
       wave_sync();  // the buffer is rewritten by the next half / the next iteration's transpose
@@ -502,6 +514,40 @@ bool fast_rgba_available(const StftParams& p) {
 // per workgroup, a slot of the 2048-point kernel being 1024 bins x 256 frames.
 uint64_t fast_rgba_scratch_bytes() { return (uint64_t)device_cu_count() * 2 * 2 * rgba_flush::kRoundBytes; }
 
+// The second launch behind a 1024-point kernel that pairs frames under an asymmetric table: one frame per transform,
+// only the units marked in p.loud_flags, colour indices into [frame][bin] rows or -- behind an image writer -- pixels
+// into the frames' image columns.
+int launch_stft_fast_loud(const StftParams& p, void* stream_v) {
+  using namespace fast1024;
+  if (p.n != 1024 || p.fast_mode != 2 || !p.twiddles || !p.loud_flags || !p.loud_only) return 1;
+  if (p.out_kind != SONO_OUT_U8_INDEX && p.out_kind != SONO_OUT_RGBA8) return 1;
+  if (p.out_kind == SONO_OUT_RGBA8 && !p.lut) return 1;
+  if (reinterpret_cast<uintptr_t>(p.out) & 3) return 1;
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_v);
+  FastScale fs = make_fast_scale(p.scale_mode, p.n, p.gain_db, p.range_db);
+  fs.xtalk = 0.0f;
+  const uint64_t need = (p.nframes + 2 * kMaxWaves - 1) / (2 * kMaxWaves);
+  const int cus = device_cu_count();
+  const uint32_t grid = (uint32_t)(need < (uint64_t)cus ? need : (uint64_t)cus);
+  const int lds_total = lds_bytes(kMaxWaves);
+  const float2* table = reinterpret_cast<const float2*>(p.fast_table);
+#define SONO_LAUNCH_S(PLUGIN, In)                                                                          \
+  do {                                                                                                      \
+    auto kern = stft1024_u8_kernel<PLUGIN, In, -1, kOutU8, true>;                                           \
+    SONO_GRANT_LDS(kern, lds_total);                                                                        \
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kMaxWaves * 64), lds_total, stream, p, fs, table);            \
+  } while (0)
+  const bool plugin = p.scale_mode == SONO_SCALE_PLUGIN_DB;
+  if (p.in_kind == SONO_IN_I16) {
+    if (plugin) SONO_LAUNCH_S(true, int16_t); else SONO_LAUNCH_S(false, int16_t);
+  } else {
+    if (plugin) SONO_LAUNCH_S(true, float); else SONO_LAUNCH_S(false, float);
+  }
+#undef SONO_LAUNCH_S
+  note_kernel("stft1024_u8_kernel<table,single,marked>");
+  return hipGetLastError() == hipSuccess ? SONO_OK : SONO_ERR_DEVICE;
+}
+
 int launch_stft_fast(const StftParams& p, void* stream_v) {
   using namespace fast1024;
   const bool rgba = p.out_kind == SONO_OUT_RGBA8, feat = p.out_kind == SONO_OUT_FEATURES;
@@ -511,7 +557,7 @@ int launch_stft_fast(const StftParams& p, void* stream_v) {
   const bool single = p.fast_mode == 2 && ((p.out_kind == SONO_OUT_U8_INDEX && !p.pair_idx_ok) || (flt && !p.pair_exact));
   // a non-linear frequency scale: colour indices only, plugin quantiser, paired frames
   const bool bank = p.fb_packed != nullptr;
-  if (bank && (p.out_kind != SONO_OUT_U8_INDEX || single || p.scale_mode != SONO_SCALE_PLUGIN_DB)) return 1;
+  if (bank && (p.out_kind != SONO_OUT_U8_INDEX || p.scale_mode != SONO_SCALE_PLUGIN_DB)) return 1;
   if (rgba) {
     if (!fast_rgba_available(p)) return 1;
     return launch_stft_fast_rgba(p, stream_v);  // the image writer is a kernel of its own (kernels_fast_rgba.hip)
@@ -562,6 +608,7 @@ int launch_stft_fast(const StftParams& p, void* stream_v) {
     if (single) {                                                                                           \
       if (p.out_kind == SONO_OUT_F32_DB) SONO_LAUNCH_T(PLUGIN, In, -1, kOutDb, true);                       \
       else if (p.out_kind == SONO_OUT_F32_MAG) SONO_LAUNCH_T(PLUGIN, In, -1, kOutMag, true);                \
+      else if (bank) SONO_LAUNCH_T(true, In, -1, kOutU8Bank, true);                                         \
       else SONO_LAUNCH_T(PLUGIN, In, -1, kOutU8, true);                                                     \
     } else if (p.hop == 256) SONO_LAUNCH_H(PLUGIN, In, 8);                                                  \
     else if (p.hop == 512) SONO_LAUNCH_H(PLUGIN, In, 16);                                                   \
@@ -577,10 +624,11 @@ int launch_stft_fast(const StftParams& p, void* stream_v) {
 #undef SONO_LAUNCH_H
 #undef SONO_LAUNCH_O
 #undef SONO_LAUNCH_T
-  note_kernel(single ? "stft1024_u8_kernel<table,single>"
+  note_kernel(single ? (bank ? "stft1024_u8_kernel<table,single,bank>" : "stft1024_u8_kernel<table,single>")
               : bank ? (tab ? "stft1024_u8_kernel<table,bank>" : "stft1024_u8_kernel<roots,bank>")
               : tab  ? "stft1024_u8_kernel<table>"
                      : "stft1024_u8_kernel<roots>");
+  note_marking(tab && !single && !bank && p.out_kind == SONO_OUT_U8_INDEX && p.loud_flags != nullptr);
   return hipGetLastError() == hipSuccess ? SONO_OK : SONO_ERR_DEVICE;
 }
 

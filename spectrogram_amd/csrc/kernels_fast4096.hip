@@ -28,6 +28,7 @@
 #include "sono_fft32.h"
 #include "sono_internal.h"
 #include "sono_launch.h"
+#include "sono_loud.h"
 
 namespace sono {
 namespace fast4096 {
@@ -242,6 +243,16 @@ __global__ __launch_bounds__(kWaves * 64) void stft4096_kernel(StftParams p, Fas
     }
 
     if (active) {
+      // (the frame's even and odd samples are transformed as one complex frame: under the asymmetric table the split
+      // carries the same kind of trace as a pair of frames does, so loud frames are marked for the launch behind this one)
+      if (p.loud_flags) {
+        float m = 0.0f;
+#pragma unroll
+        for (int a = 0; a < 16; ++a)
+          m = __builtin_fmaxf(m, __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(raw[a].x), __builtin_fabsf(raw[a].y)),
+                                                 __builtin_fmaxf(__builtin_fabsf(raw[a].z), __builtin_fabsf(raw[a].w))));
+        mark_loud(p, m > p.loud_thr_raw, p.frame0 + f, 1);
+      }
       float re[32], im[32];
       {
         const float4* win4 = reinterpret_cast<const float4*>(win_lds) + 32 * 16 * (lane >> 5) + (lane & 31);
@@ -329,6 +340,8 @@ __global__ __launch_bounds__(kWaves * 64) void stft4096_kernel(StftParams p, Fas
 
 static bool fast4096_common(const StftParams& p) {
   if (p.n != 4096 || p.nframes < 1 || p.fast_mode != 2 || !p.twiddles) return false;
+  if (!p.split_ok && !p.loud_flags) return false;  // the split's trace could show and nobody recomputes the loud frames
+  if (p.loud_only) return false;                  // (the launch that recomputes them is a one-frame-per-transform kernel)
   if (p.hop & 3) return false;  // frames start on 16-byte (float) / 8-byte (int16) boundaries
   const uintptr_t align = p.in_kind == SONO_IN_I16 ? 7 : 15;
   if (reinterpret_cast<uintptr_t>(p.pcm) & align) return false;
@@ -383,6 +396,7 @@ int launch_stft_fast4096(const StftParams& p, void* stream_v) {
 #undef SONO_L4096_I
 #undef SONO_L4096
   note_kernel(rgba ? "stft4096_kernel<image>" : "stft4096_kernel");
+  note_marking(p.loud_flags != nullptr);
   return hipGetLastError() == hipSuccess ? SONO_OK : SONO_ERR_DEVICE;
 }
 

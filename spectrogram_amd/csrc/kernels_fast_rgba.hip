@@ -32,6 +32,7 @@
 #include "sono_image_ring.h"
 #include "sono_internal.h"
 #include "sono_launch.h"
+#include "sono_loud.h"
 
 namespace sono {
 namespace fast1024r {
@@ -115,6 +116,7 @@ __global__ __launch_bounds__(kWaves * 64, 4) void stft1024_rgba_kernel(StftParam
 
   struct Unit {
     uint64_t f0;
+    uint64_t w0;  // the wavefront's first frame (wave-uniform)
     bool active, st_a, st_b, shifted;
   };
   // iteration `it` of this wavefront: four consecutive frames (two per transform).  Frames (f0, f0+1) form the complex
@@ -125,6 +127,7 @@ __global__ __launch_bounds__(kWaves * 64, 4) void stft1024_rgba_kernel(StftParam
     // of samples, so the 3/4 overlap between neighbouring groups is re-read while it is still in cache
     const uint64_t group = ((uint64_t)vb * rounds * kTileIters + it) * kWaves + wave;
     const uint64_t pair0 = group * 2;
+    u.w0 = group * 4;
     u.active = it < rounds * kTileIters && pair0 < npairs;  // wave-uniform
     if (!u.active) {            // nothing left: point at frame 0 so that the sample loads stay in bounds
       u.f0 = 0;
@@ -192,9 +195,7 @@ __global__ __launch_bounds__(kWaves * 64, 4) void stft1024_rgba_kernel(StftParam
     const Unit nxt = locate(it + 1);
     // iteration 1: every wavefront has read its quarters 2, 3 of the previous round (end of its iteration 0), so the slot
     // may be overwritten from here on
-#ifndef SONO_EXP_NOBARRIER
     if (sub == 1) __syncthreads();
-#endif
     // (the empty asm is a use of the sample registers: the wait for their loads lands here, before the image stores
     // of this iteration, and not behind them)
 #pragma unroll
@@ -206,6 +207,9 @@ __global__ __launch_bounds__(kWaves * 64, 4) void stft1024_rgba_kernel(StftParam
     }
 
     if (cur.active) {
+      if constexpr (TABLE) {  // an asymmetric table: mark the loud units for the one-frame-per-transform launch behind this one
+        if (p.loud_flags) mark_loud(p, max_abs(raw) > p.loud_thr_raw, p.frame0 + cur.w0, 4);
+      }
       float re[32], im[32];
       {
         float win[32];
@@ -313,9 +317,7 @@ __global__ __launch_bounds__(kWaves * 64, 4) void stft1024_rgba_kernel(StftParam
     } else {
       // the round's slot is complete once every wavefront is here; then take the first two quarters (after the last
       // round: of the empty round that only has the frames the last one left behind)
-#ifndef SONO_EXP_NOBARRIER
       __syncthreads();
-#endif
       if (round <= rounds) read_rows(fq, 0, round);
     }
   }
@@ -363,6 +365,7 @@ int launch_stft_fast_rgba(const StftParams& p, void* stream_v) {
 #undef SONO_LAUNCH_HOP
 #undef SONO_LAUNCH_T
   note_kernel(tab ? "stft1024_rgba_kernel<table>" : "stft1024_rgba_kernel<roots>");
+  note_marking(tab && p.loud_flags != nullptr);
   return hipGetLastError() == hipSuccess ? SONO_OK : SONO_ERR_DEVICE;
 }
 

@@ -78,6 +78,7 @@ __global__ __launch_bounds__(kThreads) void stft_general_kernel(StftParams p, Fa
   const uint32_t count = (uint32_t)min((uint64_t)frames_per_block, p.nframes - first);
   const uint32_t nb = p.bin_hi - p.bin_lo;
   const double two_over_n = 2.0 / (double)n;
+  const ExactPred pred = make_exact_pred(p.scale_mode, n, p.gain_db, p.range_db);  // (exact flavour: see sono_device.h)
 
   // fix-up pass over a SONO_OUT_FEATURES output of a float32 kernel (frames_per_block == kThreads): only the
   // records it marked (reserved[0] != 0) are recomputed
@@ -218,8 +219,8 @@ __global__ __launch_bounds__(kThreads) void stft_general_kernel(StftParams p, Fa
           idx = fb_index<A>(r, p, fs, two_over_n);
         } else if constexpr (sizeof(A) == 8) {
           idx = (p.scale_mode == SONO_SCALE_WORKER_LOG5)
-                    ? worker_index_exact(r, i)
-                    : plugin_index_exact(plugin_mag_exact(r, i, two_over_n), p.gain_db, p.range_db);
+                    ? worker_index_exact_p(r, i, pred)
+                    : plugin_index_exact_p(r, i, two_over_n, p.gain_db, p.range_db, pred);
         } else {
           idx = fast_index(r * r + i * i, fs);
         }

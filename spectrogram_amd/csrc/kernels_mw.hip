@@ -26,6 +26,7 @@
 #include "sono_device.h"
 #include "sono_internal.h"
 #include "sono_launch.h"
+#include "sono_loud.h"
 
 namespace sono {
 namespace mw {
@@ -150,6 +151,17 @@ __global__ __launch_bounds__((1 << LOG2N) / 16 * G, 4) void stft_mw_kernel(StftP
       f0 -= 1;
       st_a = false;
     }
+    if constexpr (SINGLE && OUT == kOutU8) {
+      // the second launch behind a kernel that pairs frames (or splits them): only the units it marked
+      // (StftParams::loud_flags).  The test is made per wavefront, for every frame its groups hold, so that the lanes of
+      // a wavefront stay together; a workgroup of several wavefronts per transform holds one frame, so it is uniform there.
+      if (p.loud_only) {
+        constexpr int kPerWave = TN >= 64 ? 1 : 64 / TN;
+        const uint64_t first = TN >= 64 ? base + grp : base + (threadIdx.x >> 6) * kPerWave;
+        const uint64_t last = first + kPerWave - 1 < p.nframes ? first + kPerWave - 1 : p.nframes - 1;
+        if (first >= p.nframes || !is_loud(p, p.frame0 + first, (uint32_t)(last - first + 1))) continue;
+      }
+    }
     const In* xa = x + (p.frame0 + f0) * p.hop + t;
     float re[16], im[16];
     if constexpr (SINGLE) {
@@ -241,7 +253,7 @@ __global__ __launch_bounds__((1 << LOG2N) / 16 * G, 4) void stft_mw_kernel(StftP
 #pragma unroll
     for (int m = 0; m < (N / 8) / TN; ++m) {
       const int k = 4 * (t + TN * m);
-      if (BANK || (k >= (int)p.bin_lo && k < (int)p.bin_hi)) {  // (BANK: a tap may lie outside the band)
+      if (BANK || (k + 3 >= (int)p.bin_lo && k < (int)p.bin_hi)) {  // (BANK: a tap may lie outside the band; an image's band may cut a quad)
         uint32_t wa = 0, wb = 0;
         float fa[4] = {0, 0, 0, 0}, fb[4] = {0, 0, 0, 0};
         const int cellZ = k + (k >> 5);  // + B (k is a multiple of 4)
@@ -291,8 +303,12 @@ __global__ __launch_bounds__((1 << LOG2N) / 16 * G, 4) void stft_mw_kernel(StftP
           if (st_a) *reinterpret_cast<float4*>(o + row_a) = make_float4(fa[0], fa[1], fa[2], fa[3]);
           if (!SINGLE && active) *reinterpret_cast<float4*>(o + row_b) = make_float4(fb[0], fb[1], fb[2], fb[3]);
         } else if constexpr (!FEAT) {
-          if (st_a) *reinterpret_cast<uint32_t*>(out + row_a + col) = wa;
-          if (!SINGLE && active) *reinterpret_cast<uint32_t*>(out + row_b + col) = wb;
+          if (SINGLE && p.out_kind == SONO_OUT_RGBA8) {  // the second launch behind an image writer: the frame's column
+            if (st_a) store_column_pixels(p, f0, k, wa);
+          } else {
+            if (st_a) *reinterpret_cast<uint32_t*>(out + row_a + col) = wa;
+            if (!SINGLE && active) *reinterpret_cast<uint32_t*>(out + row_b + col) = wb;
+          }
         }
       }
     }
@@ -403,12 +419,16 @@ bool mw_u8_available(const StftParams& p) {
 
 int launch_stft_mw(const StftParams& p, void* stream_v) {
   using namespace mw;
-  const bool u8 = p.out_kind == SONO_OUT_U8_INDEX, feat = p.out_kind == SONO_OUT_FEATURES;
+  // the second launch behind a kernel that pairs or splits frames: one frame per transform, marked units only, colour
+  // indices into rows or -- behind an image writer -- pixels into the frames' image columns
+  const bool marked = p.loud_only && p.loud_flags && !p.fb_packed &&
+                      (p.out_kind == SONO_OUT_U8_INDEX || (p.out_kind == SONO_OUT_RGBA8 && p.lut));
+  const bool u8 = p.out_kind == SONO_OUT_U8_INDEX || marked, feat = p.out_kind == SONO_OUT_FEATURES;
   const bool flt = p.out_kind == SONO_OUT_F32_DB || p.out_kind == SONO_OUT_F32_MAG;
   if (!(u8 || feat || flt)) return 1;
   // one frame per transform where two would not do: float32 outputs under an asymmetric table (StftParams::pair_exact),
   // colour indices under a table whose cross-talk could show (StftParams::pair_idx_ok)
-  const bool single = (flt && !p.pair_exact) || (u8 && !p.pair_idx_ok);
+  const bool single = (flt && !p.pair_exact) || (u8 && !p.pair_idx_ok) || marked;
   // a non-linear frequency scale: colour indices only, plugin quantiser
   const bool bank = p.fb_packed != nullptr;
   if (bank && (!u8 || p.scale_mode != SONO_SCALE_PLUGIN_DB)) return 1;
@@ -416,6 +436,8 @@ int launch_stft_mw(const StftParams& p, void* stream_v) {
     if ((p.n != 512 && p.n != 2048 && p.n != 4096) || !p.mw_ok || !p.twiddles || (p.bin_lo & 3) || (p.bin_hi & 3) ||
         p.bin_lo >= p.bin_hi || p.nframes < 2)
       return 1;
+  } else if (marked && p.out_kind == SONO_OUT_RGBA8) {  // (an image's band need not be whole groups of four bins)
+    if ((p.n != 512 && p.n != 2048 && p.n != 4096) || !p.mw_ok || !p.twiddles || p.nframes < 1) return 1;
   } else if (!mw_u8_available(p)) {
     return 1;
   }
@@ -466,7 +488,9 @@ int launch_stft_mw(const StftParams& p, void* stream_v) {
 #undef SONO_MW_IN
 #undef SONO_MW_M
 #undef SONO_MW
-  if (bank)
+  if (marked)
+    note_kernel(p.n == 4096 ? "stft_mw_kernel<4096,single,marked>" : p.n == 2048 ? "stft_mw_kernel<2048,single,marked>" : "stft_mw_kernel<512,single,marked>");
+  else if (bank)
     note_kernel(single ? (p.n == 4096 ? "stft_mw_kernel<4096,single,bank>" : p.n == 2048 ? "stft_mw_kernel<2048,single,bank>" : "stft_mw_kernel<512,single,bank>")
                        : (p.n == 4096 ? "stft_mw_kernel<4096,bank>" : p.n == 2048 ? "stft_mw_kernel<2048,bank>" : "stft_mw_kernel<512,bank>"));
   else

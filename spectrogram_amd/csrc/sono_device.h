@@ -41,6 +41,61 @@ __device__ __forceinline__ uint32_t plugin_index_exact(float m, double gain, dou
   return (uint32_t)((long long)trunc(v) & 255);
 }
 
+// The exact quantisers behind a float32 predictor.  Both are floor() of a smooth function t of the bin's float32
+// (re, im): a float32 evaluation of t (|X|^2 by one FMA, v_log_f32, one FMA) lies within `tol` of the double one --
+// 2 ulp of |X|^2, 1 ulp of a logarithm of magnitude < 64 (4e-6), times the slope a, plus the rounding of t itself
+// (below 3e-5 at t = 256) -- so whenever that t is further than `tol` from every integer, floor() of both is the same
+// integer and the double sqrt / log10 (the long half of the exact kernels) are skipped; `tol` carries a fivefold
+// margin.  Everything else -- t near an integer (which includes both clamps and the plugin's 256 -> 0 wrap at
+// r == -gain), zero, infinite and NaN inputs -- takes the double route unchanged, so the result is the reference's
+// integer in every case.  Not used where the plugin's magnitude floor of 1e-12 (-240 dB) lies inside the display range.
+struct ExactPred {
+  float a, b, tol;
+  uint32_t on;
+};
+__host__ __device__ inline ExactPred make_exact_pred(uint32_t mode, uint32_t n, double gain, double range) {
+  ExactPred q;
+  const double l10_2 = 0.30102999566398119521;
+  if (mode == SONO_SCALE_WORKER_LOG5) {
+    q.a = (float)(255.0 * 0.5 * l10_2 / 5.0);  // t = 255 * log10|X| / 5
+    q.b = 0.0f;
+    q.on = 1;
+  } else {
+    const double lg = 2.0 * (1.0 - log2((double)n));  // t = (20 log10(2/N |X|) + gain) / range * 255 + 256
+    q.a = (float)(10.0 * l10_2 * 255.0 / range);
+    q.b = (float)((10.0 * l10_2 * lg + gain) * 255.0 / range + 256.0);
+    q.on = (gain + range < 230.0 && range > 0.0) ? 1u : 0u;
+  }
+  q.tol = 1e-3f + 2e-5f * (q.a < 0 ? -q.a : q.a);
+  if (!(q.tol < 0.25f)) q.on = 0;
+  return q;
+}
+__device__ __forceinline__ uint32_t worker_index_exact_p(float re, float im, const ExactPred& q) {
+#ifdef SONO_EXP_NOPRED
+  return worker_index_exact(re, im);
+#endif
+  const float t = __log2f(__builtin_fmaf(re, re, im * im)) * q.a;
+  const float fr = __builtin_amdgcn_fractf(t);
+  if (t > q.tol && t < 255.0f - q.tol && fr > q.tol && fr < 1.0f - q.tol) return (uint32_t)t;
+  if (t < -q.tol) return 0;            // |X| < 1
+  if (t > 255.0f + q.tol) return 255;  // |X| > 1e5
+  return worker_index_exact(re, im);
+}
+__device__ __forceinline__ uint32_t plugin_index_exact_p(float re, float im, double two_over_n, double gain, double range,
+                                                         const ExactPred& q) {
+#ifdef SONO_EXP_NOPRED
+  return plugin_index_exact(plugin_mag_exact(re, im, two_over_n), gain, range);
+#endif
+  if (q.on) {
+    const float t = __builtin_fmaf(__log2f(__builtin_fmaf(re, re, im * im)), q.a, q.b);
+    const float fr = __builtin_amdgcn_fractf(t);
+    if (t > 1.0f + q.tol && t < 256.0f - q.tol && fr > q.tol && fr < 1.0f - q.tol) return (uint32_t)t;
+    if (t < 1.0f - q.tol) return 0;      // r < -gain - range (and the 1e-12 floor lies below the display range)
+    if (t > 256.0f + q.tol) return 255;  // r > -gain
+  }
+  return plugin_index_exact(plugin_mag_exact(re, im, two_over_n), gain, range);
+}
+
 // Feature pass, reduction of per-lane (largest |X|^2, its bin, runner-up) over the `width` lanes that share a frame:
 // larger value wins, equal values go to the lower bin (the strict-> first-wins rule over ascending bins); the
 // frame's runner-up is the largest of the losers' bests and the winner's own runner-up.

@@ -16,6 +16,7 @@ int fill_window(uint32_t id, uint32_t n, double alpha, float* w);
 int fill_twiddles(uint32_t mode, uint32_t n, double* c, double* s);
 int compute_geometry(uint32_t n, uint32_t hop, uint32_t rule, uint32_t bin_lo, uint32_t bin_hi, uint64_t L,
                      sono_geometry* g);
+void pair_defect_gains(uint32_t n, const double* c, const double* s, const float* window, double* g_raw, double* g_win);
 
 // One launch of an STFT kernel: frames [frame0, frame0 + nframes) of one signal.
 struct StftParams {
@@ -62,15 +63,32 @@ struct StftParams {
   uint32_t fixup;         // != 0: recompute only the feature records a float32 kernel marked (reserved[0] != 0); for
                           // launch_features_fixup the capacity of the queue's list
   double gain_db, range_db;
+  // Two frames per transform under a twiddle table that is not conjugate-symmetric (the plugin's recurrence factors): a
+  // frame's spectrum picks up a trace of its partner's and of its own mirror image, bounded by pair_defect_gains() times
+  // the largest sample.  Where that bound could move a colour index by a whole step, the kernels that pair frames (or
+  // split one frame into its even and odd samples) mark the loud units -- one byte per group of four frames,
+  // loud_flags[(frame >> 2) & loud_mask] -- and a second launch of a one-frame-per-transform kernel (loud_only != 0)
+  // recomputes just those.  loud_flags == nullptr: nothing to mark (symmetric table, or the bound is harmless).
+  uint8_t* loud_flags;
+  uint32_t loud_mask;
+  float loud_thr_raw;     // a lane's largest |sample| above this marks the unit
+  float loud_thr_win;     // ... or its largest |sample * window| above this (kernels that keep no raw samples)
+  uint32_t loud_only;     // the second launch: units without a mark are skipped
+  uint32_t split_ok;      // 4096 points: a frame may be transformed as its even and odd samples in one complex frame
+                          // without marks (symmetric table, or a display floor its defect cannot reach)
 };
 
 // Every launch_* function reports the kernel it enqueued (a static string), for sono_kernel_route.
 void note_kernel(const char* name);
+// ... and whether that kernel marks loud units in StftParams::loud_flags (a launch of one that does not needs no second pass).
+void note_marking(bool marks);
 
 // kernels_general.hip: table-driven radix-2 dataflow, any power-of-two size, both arithmetics.
 int launch_stft_general(const StftParams& p, bool exact_f64, void* hip_stream);
 // kernels_fast.hip: float32 kernels with accurate twiddles (returns 1 if this size/mode has no fast kernel).
 int launch_stft_fast(const StftParams& p, void* hip_stream);
+// ... and the launch behind it that recomputes the units it marked, one frame per transform (StftParams::loud_flags).
+int launch_stft_fast_loud(const StftParams& p, void* hip_stream);
 void build_fast_table_1024(std::vector<float>& t);
 // kernels_fast_rgba.hip: the 1024-point kernel that writes the RGBA image itself, colour-index exchange in LDS.
 int launch_stft_fast_rgba(const StftParams& p, void* hip_stream);
@@ -98,10 +116,10 @@ bool mw_u8_available(const StftParams& p);
 int launch_features_fixup(const StftParams& p, void* hip_stream, bool listed = false);
 bool features_fixup_available(const StftParams& p);
 uint64_t features_fixup_queue_bytes(uint32_t capacity);
-// kernels_exact.hip: the exact arithmetic for 1024-point frames, two in-register passes (returns 1 if it does not
+// kernels_exact.hip: the exact arithmetic for 512 / 1024 / 2048 / 4096-point frames, two in-register passes (returns 1 if it does not
 // serve this launch; results are bit-identical to launch_stft_general(p, true, ...)).
 int launch_stft_exact(const StftParams& p, void* hip_stream);
-bool exact1024_available(const StftParams& p);
+bool exact_available(const StftParams& p);
 // kernels_post.hip
 int launch_resample(const uint8_t* in, uint64_t in_frames, uint32_t bins, uint64_t out_width, uint64_t col0, uint64_t ncols,
                     uint8_t* out, void* hip_stream);

@@ -94,7 +94,9 @@ def test_fft4096_kernel_indices_and_image(hop, in_kind, round_frames, monkeypatc
     with plugin_engine(n, hop, **kw) as eng:
         got = eng.stft(src)
         route = eng.kernel_route()
-    assert route == ("stft4096_kernel" if hop % 4 == 0 else "stft_mw_kernel<4096,single>"), route
+    # (the kernel splits a frame into its even and odd samples; under the recurrence table that split is safe only below a
+    # sample level, so it marks the loud frames -- this signal is loud -- and a one-frame-per-transform launch redoes them)
+    assert route == ("stft4096_kernel + stft_mw_kernel<4096,single,marked>" if hop % 4 == 0 else "stft_mw_kernel<4096,single>"), route
     d = np.abs(got.astype(np.int16) - ref.astype(np.int16))
     d = np.minimum(d, 256 - d)
     assert got.shape == ref.shape and d.max() <= 1 and (d != 0).mean() < 0.02
@@ -106,7 +108,7 @@ def test_fft4096_kernel_indices_and_image(hop, in_kind, round_frames, monkeypatc
             route = eng.kernel_route()
         want = lut.reshape(256, 4)[got[:, lo:hi].T[::-1]]
         if hop % 4 == 0:
-            assert route == "stft4096_kernel<image>:rgba", route
+            assert route == "stft4096_kernel<image>:rgba + stft_mw_kernel<4096,single,marked>", route
             assert img.shape == want.shape and np.array_equal(img, want)          # same arithmetic, same indices
         else:
             assert route == "stft_mw_kernel<4096,single>:u8 + colorize_kernel", route

@@ -249,6 +249,32 @@ def test_float32_db_bounds_down_to_the_display_floor(n):
     assert seen_low > 1000          # the zone is populated, not vacuously true
 
 
+@pytest.mark.parametrize("n", [512, 1024, 2048, 4096])
+def test_colour_indices_within_one_lsb_under_near_full_scale_tones(n):
+    """The case that needs the one-frame-per-transform launch: a tone near full scale over a noise floor at the bottom of
+    the display range.  Transformed two frames at a time (or, at 4096 points, as even and odd samples) under the
+    plugin's recurrence factors, such frames came out 2 LSB off the reference in about one pixel in 10^5 -- the bins
+    within a few dB of the -100 dB floor that sit where the table's Hermitian defect puts the tone's image.  With the
+    loud units marked and recomputed (1024, 4096 points) or every frame transformed alone (512, 2048 points) every
+    pixel is within 1 LSB, for random tone frequencies, phases, levels and floors."""
+    hop = n // 4
+    rng = np.random.default_rng(n + 1)
+    L = n + hop * 31 + 1
+    t = np.arange(L, dtype=np.float64)
+    with plugin_engine(n, hop, F.ARITH_FAST_F32) as eng:
+        for trial in range(24):
+            f = rng.uniform(0.02, 0.48)
+            amp = (0.95, 0.95, 0.5, 0.25)[trial % 4]
+            noise = (3e-4, 1e-3, 2e-3)[trial % 3]
+            x = (amp * np.sin(2 * np.pi * f * t + rng.uniform(0, 6)) + noise * rng.uniform(-1, 1, L)).astype(np.float32)
+            ref = oracle.plugin_get_frequencies(x, n, n - hop)
+            d = cyc_diff(eng.stft(x), ref)
+            assert d.max() <= 1 and (d != 0).mean() < 0.02, (n, trial, f, amp, noise, int((d > 1).sum()))
+        route = eng.kernel_route()
+    assert route == {512: "stft_mw_kernel<512,single>", 1024: "stft1024_u8_kernel<table> + stft1024_u8_kernel<table,single,marked>",
+                     2048: "stft_mw_kernel<2048,single>", 4096: "stft4096_kernel + stft_mw_kernel<4096,single,marked>"}[n], route
+
+
 def test_plugin_accurate_twiddles_differ_from_recurrence_at_4096():
     """The recurrence twiddles are part of the reference's result: at 4096 points they sit up to 3e-5
     away from the true roots of unity, which moves visible bins by more than the 0.01 dB tolerance, so
@@ -425,7 +451,8 @@ def test_kernel_route_is_visible_and_default_view_is_fast():
         assert eng.kernel_route() == ""
         eng.set_colormap(lut)
         img = eng.stft(x)
-        assert eng.kernel_route() == "stft1024_rgba_kernel<table>:rgba"
+        # (+ the launch that recomputes, one frame per transform, the units the image writer marked as loud)
+        assert eng.kernel_route() == "stft1024_rgba_kernel<table>:rgba + stft1024_u8_kernel<table,single,marked>"
     want = ref[:, lo:hi].T[::-1].astype(np.int16)
     l4 = lut.reshape(256, 4)
     ok = np.zeros(want.shape, bool)
@@ -440,7 +467,7 @@ def test_kernel_route_is_visible_and_default_view_is_fast():
         assert eng.kernel_route() == "stft1024_rgba_kernel<roots>:rgba + stft_general_kernel<float>"   # + the wrapped last frame
     with plugin_engine(4096, 256, F.ARITH_FAST_F32, out_kind=F.OUT_RGBA8, bin_lo=160, bin_hi=1280) as eng:
         eng.stft(x)
-        assert eng.kernel_route() == "stft4096_kernel<image>:rgba"
+        assert eng.kernel_route() == "stft4096_kernel<image>:rgba + stft_mw_kernel<4096,single,marked>"
     with plugin_engine(256, 64, F.ARITH_FAST_F32) as eng:
         eng.stft(x)
         assert eng.kernel_route() == "stft_general_kernel<float>"
@@ -450,22 +477,28 @@ def test_kernel_route_is_visible_and_default_view_is_fast():
 
 
 def test_one_frame_per_transform_where_pairing_would_leak():
-    """Under the plugin's recurrence table (fft.js:149-164) two frames that share a complex transform leak into each
-    other at asymmetry x sum|w|.  A rectangular window at 1024 points puts that above the display floor of the
-    default gain / range, and float32 dB output has no floor at all: those contexts run the 1024-point kernel with
-    one real frame per transform, whose spectrum is the reference's own transform of that frame."""
+    """Under the plugin's recurrence table (spectrogram.esm.js:176-190) the transform of a real frame is not exactly
+    Hermitian, so two frames that share a complex transform do not separate exactly: a bin is off by at most g x the
+    pair's largest sample (g: the defect's operator norm for this table and window, computed when the context is made).
+    At the default gain / range that could move a colour index near the -100 dB floor by more than a step once samples
+    exceed a few hundredths of full scale, so the 1024-point kernel marks the loud units and a second launch recomputes
+    them with one real frame per transform, whose spectrum is the reference's own transform of that frame; a display
+    floor the defect cannot reach keeps the pairs alone; float32 dB output has no floor at all and never pairs; the
+    sizes whose kernels do not mark transform one frame at a time throughout."""
     rng = np.random.default_rng(1024)
     L = 1024 + 256 * 700 + 3
     x = (rng.standard_normal(L) * 1e-4).astype(np.float32)
     x[256 * 200:256 * 200 + 1024] += 0.9 * np.sin(np.arange(1024) * 0.61).astype(np.float32)   # one loud frame span
-    ref = oracle.plugin_get_frequencies(x, 1024, 768, window="rectangular")
-    with plugin_engine(1024, 256, F.ARITH_FAST_F32, window="rectangular") as eng:
-        got = eng.stft(x)
-        assert eng.kernel_route() == "stft1024_u8_kernel<table,single>"
-    assert got.shape == ref.shape and cyc_diff(got, ref).max() <= 1
-    assert (got == ref).mean() > 0.98
-    # the Hann window at the same settings keeps the paired flavour
-    with plugin_engine(1024, 256, F.ARITH_FAST_F32) as eng:
+    both = "stft1024_u8_kernel<table> + stft1024_u8_kernel<table,single,marked>"
+    for window in ("rectangular", "hann"):
+        ref = oracle.plugin_get_frequencies(x, 1024, 768, window=window)
+        with plugin_engine(1024, 256, F.ARITH_FAST_F32, window=window) as eng:
+            got = eng.stft(x)
+            assert eng.kernel_route() == both
+        assert got.shape == ref.shape and cyc_diff(got, ref).max() <= 1
+        assert (got == ref).mean() > 0.98
+    # a floor of -60 dB: the defect of full-scale samples stays below a twentieth of a step there; pairs alone
+    with plugin_engine(1024, 256, F.ARITH_FAST_F32, gain=0.0, rng=60.0) as eng:
         eng.stft(x)
         assert eng.kernel_route() == "stft1024_u8_kernel<table>"
     # float32 dB under the table: single flavour, 0.01 dB where the bin is within 75 dB of its frame's peak
@@ -496,10 +529,11 @@ def test_one_frame_per_transform_where_pairing_would_leak():
 @pytest.mark.parametrize("hop,frames", [(256, 16), (256, 17), (512, 33), (100, 130), (333, 67), (768, 35)])
 @pytest.mark.parametrize("i16", [False, True])
 def test_one_frame_and_filter_bank_flavours_over_hops_inputs_and_lengths(flavour, hop, frames, i16):
-    """The 1024-point index kernel's one-frame-per-transform flavour (rectangular window under the plugin's table)
-    and its filter-bank flavour (mel): hops with and without the shared sample run (multiples of 32 or not), float32
-    and int16 samples, frame counts from the smallest the kernel takes (16) over odd counts to a few rounds of the
-    grid; a band of whole groups of four bins.  Within 1 LSB of the checker."""
+    """The 1024-point index kernel's one-frame-per-transform flavour -- as the launch that recomputes the units the
+    pairing kernel marked (this signal is loud throughout, so all of them), and with the filter bank (mel) -- over hops
+    with and without the shared sample run (multiples of 32 or not), float32 and int16 samples, frame counts from the
+    smallest the kernel takes (16) over odd counts to a few rounds of the grid; a band of whole groups of four bins.
+    Within 1 LSB of the checker."""
     n, sr = 1024, 250000
     rng = np.random.default_rng(hop * 7 + frames)
     L = n + hop * (frames - 1) + int(rng.integers(0, hop))
@@ -514,13 +548,13 @@ def test_one_frame_and_filter_bank_flavours_over_hops_inputs_and_lengths(flavour
     kw = dict(in_kind=F.IN_I16 if i16 else F.IN_F32, bin_lo=lo, bin_hi=hi)
     if flavour == "single":
         ref = oracle.plugin_get_frequencies(x, n, n - hop, window="rectangular")
-        route = "stft1024_u8_kernel<table,single>"
+        route = "stft1024_u8_kernel<table> + stft1024_u8_kernel<table,single,marked>"
         with plugin_engine(n, hop, F.ARITH_FAST_F32, window="rectangular", **kw) as eng:
             got = eng.stft(x_in)
             assert eng.kernel_route() == route
     else:
         ref = oracle.plugin_get_frequencies_scaled(x, n, n - hop, "mel", sr)
-        route = "stft1024_u8_kernel<table,bank>"
+        route = "stft1024_u8_kernel<table,single,bank>"
         with plugin_engine(n, hop, F.ARITH_FAST_F32, **kw) as eng:
             eng.set_filterbank(*E.filterbank_table("mel", n, sr))
             got = eng.stft(x_in)
@@ -775,8 +809,8 @@ def test_scaled_frequencies_stay_on_the_float32_kernels(n, hop, scale):
     """A non-linear frequency scale in the float32 arithmetic: the index kernel (1024 points) or the three-pass kernel
     (other sizes) gathers the two taps of every output bin itself; an index band that is not made of whole groups of
     four bins goes through a plane of magnitudes and the filter-bank kernel.  The general kernel is not involved (at
-    4096 points, where the recurrence factors would let a full-scale frame leave a trace above the display floor in a
-    partner, the three-pass kernel transforms one frame at a time).  Indices within 1 LSB of the checker's, the image is the
+    the default display floor the recurrence factors would let loud frames that share a transform move each other's
+    indices by more than a step, so these flavours transform one frame at a time).  Indices within 1 LSB of the checker's, the image is the
     colour map applied to the same arithmetic's indices (any band), and a NaN sample turns every bin of the frames it
     touches into index 0."""
     rng = np.random.default_rng(n + 5)
@@ -791,8 +825,8 @@ def test_scaled_frequencies_stay_on_the_float32_kernels(n, hop, scale):
         eng.set_filterbank(*fb)
         got = eng.stft(x)
         route = eng.kernel_route()
-    fused = {1024: "stft1024_u8_kernel<table,bank>", 512: "stft_mw_kernel<512,bank>", 2048: "stft_mw_kernel<2048,bank>",
-             4096: "stft_mw_kernel<4096,single,bank>"}[n]
+    fused = {1024: "stft1024_u8_kernel<table,single,bank>", 512: "stft_mw_kernel<512,single,bank>",
+             2048: "stft_mw_kernel<2048,single,bank>", 4096: "stft_mw_kernel<4096,single,bank>"}[n]
     assert route == fused, route
     d = cyc_diff(got, ref)
     assert got.shape == ref.shape and d.max() <= 1 and (d != 0).mean() < 0.02, (d.max(), (d != 0).mean())
