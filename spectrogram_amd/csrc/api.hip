@@ -520,9 +520,10 @@ static int refresh_routes(sono_ctx* c) {
     // window).  A colour index moves by less than one step while |X| is off by less than eps = 10^(step in dB / 20) - 1
     // of its value, and the smallest value that shows is the quantiser's floor; half of that is left to float32
     // rounding.  So pairs are safe outright if full-scale samples cannot reach the bound; safe with the loud units
-    // marked and recomputed one frame per transform if a plausible level can (the kernels that mark: 1024 points, and
-    // the 4096-point kernel, which splits a frame into even and odd samples and carries the defect of the 2048-point
-    // transform inside it twice); otherwise such a context transforms one frame at a time from the start.
+    // marked and recomputed one frame per transform if a plausible level can (the register kernels at 512 / 1024 / 2048
+    // points mark, and so does the 4096-point kernel, which splits a frame into even and odd samples and carries the
+    // defect of the 2048-point transform inside it twice); otherwise such a context transforms one frame at a time
+    // from the start.
     const uint32_t n = c->cfg.fft_n;
     const bool plugin = c->cfg.scale_mode == SONO_SCALE_PLUGIN_DB;
     const double eps = plugin ? std::pow(10.0, (double)c->cfg.range_db / (255.0 * 20.0)) - 1.0 : std::pow(10.0, 5.0 / 255.0) - 1.0;
@@ -537,7 +538,7 @@ static int refresh_routes(sono_ctx* c) {
     pair_defect_gains(n, tc.data(), ts.data(), c->h_window.data(), &g_raw, &g_win);
     double thr_raw = g_raw > 0 ? crit / g_raw : 1e30, thr_win = g_win > 0 ? crit / g_win : 1e30;
     c->pair_idx_ok = thr_raw >= 1.0;
-    bool marks = !c->pair_idx_ok && n == 1024;
+    bool marks = !c->pair_idx_ok && (n == 512 || n == 1024 || n == 2048);
     if (n == 4096) {  // the kernel that splits a frame: the inner transform's table is the first eleven stages of this one
       std::vector<float> we(n / 2), wo(n / 2);
       for (uint32_t i = 0; i < n / 2; i++) {
@@ -618,7 +619,7 @@ static int launch_range(sono_ctx* c, const StftParams& q_in, const IndexScratch&
     q.loud_mask = (uint32_t)(kLoudFlagBytes - 1);
     q.loud_thr_raw = c->loud_thr_raw;
     q.loud_thr_win = c->loud_thr_win;
-    if (q.n == 1024) q.pair_idx_ok = 1;  // (4096 points: the pairing three-pass kernel stays off, the splitting kernel marks)
+    if (q.n != 4096) q.pair_idx_ok = 1;  // (4096 points: the pairing three-pass kernel stays off, the splitting kernel marks)
   }
   // clears the marks of a launch's frames before it, and recomputes the marked units behind it
   auto clear_marks = [&](const StftParams& u) -> int {
@@ -667,7 +668,38 @@ static int launch_range(sono_ctx* c, const StftParams& q_in, const IndexScratch&
     if (r < 0) return fail(c, r, "kernel launch failed: %s", hipGetErrorString(hipGetLastError()));
     if (r == SONO_OK) {
       note_route(c, ":rgba");
-      return redo_marked(qq);
+      if (!qq.loud_flags || !t_marks) return SONO_OK;
+      // The image writer marked its loud units: their colour indices are recomputed one frame per transform, a chunk
+      // of frames at a time into the context's scratch (free again behind the image writer), and the marked frames'
+      // columns are written over the image.
+      StftParams u = q;
+      u.out_kind = SONO_OUT_U8_INDEX;
+      u.bin_lo = q.bin_lo & ~3u;
+      u.bin_hi = (q.bin_hi + 3u) & ~3u;
+      u.out_bins = u.bin_hi - u.bin_lo;
+      u.out_bin0 = u.bin_lo;
+      u.lut = nullptr;
+      u.loud_only = 1;
+      u.out = c->d_aux;
+      const uint64_t nb = u.out_bins;
+      // frames per chunk, less 64 so that a last chunk of fewer than 64 frames can ride with the one before it
+      const uint64_t room = c->d_aux_bytes / nb / 64 * 64;  // (sparse rows, written and read once: the whole scratch)
+      if (room < 128) return fail(c, SONO_ERR_ARG, "the context's scratch is too small for the pass over the marked frames");
+      const uint64_t chunk = room - 64;
+      for (uint64_t f = 0; f < q.nframes; f += u.nframes) {
+        u.frame0 = q.frame0 + f;
+        u.nframes = (q.nframes - f < chunk + 64) ? q.nframes - f : chunk;
+        u.col0 = 0;
+        int r2 = u.n == 1024 ? launch_stft_fast_loud(u, c->stream) : launch_stft_mw(u, c->stream);
+        if (r2 != SONO_OK) return fail(c, r2 < 0 ? r2 : SONO_ERR_DEVICE, "launch of the pass over the marked frames failed");
+        note_route(c);
+        r2 = launch_colorize_marked((const uint8_t*)c->d_aux, u.nframes, (uint32_t)nb, u.bin_lo, q.bin_lo, q.bin_hi, q.row_of_bin0,
+                                    qq.lut, (uint8_t*)q.out, q.width, q.col0 + f, u.loud_flags, u.loud_mask, u.frame0, c->stream);
+        if (r2 != SONO_OK) return fail(c, r2, "colour-map launch over the marked frames failed");
+        sono::note_kernel("colorize_marked_kernel");
+        note_route(c);
+      }
+      return SONO_OK;
     }
     // (r == 1: no image writer took the call after all, e.g. an output pointer that is not 4-byte aligned; the
     // two-kernel route below serves it)

@@ -168,23 +168,41 @@ __global__ __launch_bounds__(kMaxWaves * 64, 4) void stft1024_u8_kernel(StftPara
       }
     }
   };
-  Unit cur = locate(0);
-  fetch(cur);
-  for (uint64_t it = 0; cur.active; ++it) {
-    const Unit nxt = locate(it + 1);
-    const uint64_t f0 = cur.f0;
-    const bool st_a = cur.st_a, st_b = SINGLE ? false : cur.st_b;
+  // The launch behind a kernel that pairs frames (p.loud_only): only the units it marked are transformed.  A wavefront
+  // looks at the marks of its next 64 units at once (lane j at unit it + j), so the unmarked stretches cost one load
+  // per 64 units and no sample is fetched for them.
+  auto next_marked = [&](uint64_t it) -> uint64_t {
     if constexpr (SINGLE && OUT == kOutU8) {
-      // the second launch behind a kernel that pairs frames: only the units it marked (StftParams::loud_flags)
-      if (p.loud_only && !is_loud(p, p.frame0 + cur.w0, 2)) {  // wave-uniform
-        fetch(nxt);
-        cur = nxt;
-        continue;
+      if (p.loud_only) {
+        while (it < iters) {
+          const uint64_t j = it + lane;
+          const uint64_t fr = p.frame0 + (((uint64_t)vb * iters + j) * kWaves + wave) * 2;  // the unit's frames: fr, fr + 1
+          bool m = false;
+          if (j < iters && fr - p.frame0 < npairs)
+            m = (p.loud_flags[(fr >> 2) & p.loud_mask] | p.loud_flags[((fr + 1) >> 2) & p.loud_mask]) != 0;
+          const uint64_t b = __builtin_amdgcn_ballot_w64(m);
+          if (b) return it + (uint64_t)__builtin_ctzll(b);
+          it += 64;
+        }
+        return iters;
       }
     }
+    return it;
+  };
+  uint64_t it = next_marked(0);
+  Unit cur = locate(it);
+  fetch(cur);
+  while (cur.active) {
+    const uint64_t it_next = next_marked(it + 1);
+    const Unit nxt = locate(it_next);
+    it = it_next;
+    const uint64_t f0 = cur.f0;
+    const bool st_a = cur.st_a, st_b = SINGLE ? false : cur.st_b;
+#ifndef SONO_EXP_NOMARK
     if constexpr (TABLE && !SINGLE && (OUT == kOutU8)) {
       if (p.loud_flags) mark_loud(p, max_abs(raw) > p.loud_thr_raw, p.frame0 + cur.w0, 4);
     }
+#endif
 
     float re[32], im[32];
     {
@@ -298,7 +316,7 @@ __global__ __launch_bounds__(kMaxWaves * 64, 4) void stft1024_u8_kernel(StftPara
         const float4 q23 = SINGLE ? make_float4(0, 0, 0, 0) : *reinterpret_cast<const float4*>(mbuf + idx + 2);
         uint32_t wa = 0, wb = 0;
         float fa[4] = {0, 0, 0, 0}, fb[4] = {0, 0, 0, 0};
-        const bool in_band = k + 3 >= (int)p.bin_lo && k < (int)p.bin_hi;  // (an image's band may start or end inside a quad)
+        const bool in_band = k >= (int)p.bin_lo && k < (int)p.bin_hi;
 #define SONO_BIN(B, ZR, ZI, PR, PI)                                          \
   {                                                                          \
     const float ar = SINGLE ? (ZR) : (ZR) + (PR), ai = SINGLE ? (ZI) : (ZI) - (PI); \
@@ -347,13 +365,9 @@ __global__ __launch_bounds__(kMaxWaves * 64, 4) void stft1024_u8_kernel(StftPara
             if (st_b) *reinterpret_cast<float4*>(o + row_b) = make_float4(fb[0], fb[1], fb[2], fb[3]);
           }
         } else if (!FEAT && !BANK && in_band) {
-          if (SINGLE && p.out_kind == SONO_OUT_RGBA8) {  // the second launch behind an image writer: the frame's column
-            if (st_a) store_column_pixels(p, f0, k, wa);
-          } else {
-            const uint32_t col = k - p.out_bin0;
-            if (st_a) *reinterpret_cast<uint32_t*>(out + row_a + col) = wa;
-            if (st_b) *reinterpret_cast<uint32_t*>(out + row_b + col) = wb;
-          }
+          const uint32_t col = k - p.out_bin0;
+          if (st_a) *reinterpret_cast<uint32_t*>(out + row_a + col) = wa;
+          if (st_b) *reinterpret_cast<uint32_t*>(out + row_b + col) = wb;
         }
       }
       wave_sync();  // the buffer is rewritten by the next half / the next iteration's transpose
@@ -515,13 +529,11 @@ bool fast_rgba_available(const StftParams& p) {
 uint64_t fast_rgba_scratch_bytes() { return (uint64_t)device_cu_count() * 2 * 2 * rgba_flush::kRoundBytes; }
 
 // The second launch behind a 1024-point kernel that pairs frames under an asymmetric table: one frame per transform,
-// only the units marked in p.loud_flags, colour indices into [frame][bin] rows or -- behind an image writer -- pixels
-// into the frames' image columns.
+// only the units marked in p.loud_flags, colour indices into [frame][bin] rows.
 int launch_stft_fast_loud(const StftParams& p, void* stream_v) {
   using namespace fast1024;
   if (p.n != 1024 || p.fast_mode != 2 || !p.twiddles || !p.loud_flags || !p.loud_only) return 1;
-  if (p.out_kind != SONO_OUT_U8_INDEX && p.out_kind != SONO_OUT_RGBA8) return 1;
-  if (p.out_kind == SONO_OUT_RGBA8 && !p.lut) return 1;
+  if (p.out_kind != SONO_OUT_U8_INDEX || !fast_u8_available(p)) return 1;
   if (reinterpret_cast<uintptr_t>(p.out) & 3) return 1;
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_v);
   FastScale fs = make_fast_scale(p.scale_mode, p.n, p.gain_db, p.range_db);

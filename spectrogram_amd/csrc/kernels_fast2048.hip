@@ -22,6 +22,7 @@
 #include "sono_device.h"
 #include "sono_internal.h"
 #include "sono_launch.h"
+#include "sono_loud.h"
 #include "sono_rgba_flush.h"
 
 namespace sono {
@@ -363,10 +364,12 @@ __global__ __launch_bounds__(kWaves * 64) void stft2048_kernel(StftParams p, Fas
     float re[32], im[32];
     {
       const In* x0 = x + (p.frame0 + fb) * p.hop + lane;
+      float loudest = 0.0f;  // TABLE: this lane's largest |sample| (the wavefront's two frames are marked if it is loud)
       if constexpr (HOP64 > 0) {
         float raw[32 + HOP64];
 #pragma unroll
         for (int a = 0; a < 32 + HOP64; ++a) raw[a] = ld<In>(x0, 64 * a);
+        if constexpr (TABLE) loudest = max_abs(raw);
 #pragma unroll
         for (int a = 0; a < 32; ++a) {
           const float w = win_lds[64 * a + lane];
@@ -378,9 +381,14 @@ __global__ __launch_bounds__(kWaves * 64) void stft2048_kernel(StftParams p, Fas
 #pragma unroll
         for (int a = 0; a < 32; ++a) {
           const float w = win_lds[64 * a + lane];
-          re[brev5(a)] = ld<In>(x0, 64 * a) * w;
-          im[brev5(a)] = ld<In>(x1, 64 * a) * w;
+          const float v0 = ld<In>(x0, 64 * a), v1 = ld<In>(x1, 64 * a);
+          if constexpr (TABLE) loudest = __builtin_fmaxf(loudest, __builtin_fmaxf(__builtin_fabsf(v0), __builtin_fabsf(v1)));
+          re[brev5(a)] = v0 * w;
+          im[brev5(a)] = v1 * w;
         }
+      }
+      if constexpr (TABLE) {  // an asymmetric table: see StftParams::loud_flags
+        if (p.loud_flags) mark_loud(p, loudest > p.loud_thr_raw, p.frame0 + f0, 2);
       }
     }
     int lt = lane;
@@ -585,6 +593,9 @@ __global__ __launch_bounds__(kWaves * 64) void stft2048_rgba_kernel(StftParams p
       }
     }
     if (f0 < p.nframes) {  // wave-uniform
+      if constexpr (TABLE) {  // an asymmetric table: see StftParams::loud_flags
+        if (p.loud_flags) mark_loud(p, max_abs(raw) > p.loud_thr_raw, p.frame0 + f0, 2);
+      }
       float re[32], im[32];
 #pragma unroll
       for (int a = 0; a < 32; ++a) {
@@ -718,6 +729,7 @@ int launch_stft_fast2048(const StftParams& p, void* stream_v) {
 #undef SONO_R2048_T
 #undef SONO_R2048
     note_kernel(tab ? "stft2048_rgba_kernel<table>" : "stft2048_rgba_kernel<roots>");
+    note_marking(tab && p.loud_flags != nullptr);
     return hipGetLastError() == hipSuccess ? SONO_OK : SONO_ERR_DEVICE;
   }
 #define SONO_L2048(PL, In, FE, H)                                                                               \
@@ -741,6 +753,7 @@ int launch_stft_fast2048(const StftParams& p, void* stream_v) {
 #undef SONO_L2048_T
 #undef SONO_L2048
   note_kernel(tab ? "stft2048_kernel<table>" : "stft2048_kernel<roots>");
+  note_marking(tab && p.out_kind == SONO_OUT_U8_INDEX && p.loud_flags != nullptr);
   return hipGetLastError() == hipSuccess ? SONO_OK : SONO_ERR_DEVICE;
 }
 

@@ -22,6 +22,7 @@
 #include "sono_device.h"
 #include "sono_internal.h"
 #include "sono_launch.h"
+#include "sono_loud.h"
 #include "sono_fft32.h"
 #include "sono_image_ring.h"
 
@@ -283,10 +284,12 @@ __global__ __launch_bounds__(kWaves * 64) void stft512_kernel(StftParams p, Fast
         win[4 * j] = v.x; win[4 * j + 1] = v.y; win[4 * j + 2] = v.z; win[4 * j + 3] = v.w;
       }
       const In* x0 = x + (p.frame0 + fb) * p.hop + l;
+      float loudest = 0.0f;  // TABLE: this lane's largest |sample| (the wavefront's eight frames are marked if it is loud)
       if constexpr (HOP32 > 0) {
         float raw[16 + 3 * HOP32];
 #pragma unroll
         for (int a = 0; a < 16 + 3 * HOP32; ++a) raw[a] = ld<In>(x0, 32 * a);
+        if constexpr (TABLE) loudest = max_abs(raw);
 #pragma unroll
         for (int a = 0; a < 16; ++a) {
           re[brev4(a)] = raw[a] * win[a];
@@ -298,11 +301,18 @@ __global__ __launch_bounds__(kWaves * 64) void stft512_kernel(StftParams p, Fast
         const In *x1 = x0 + p.hop, *x2 = x1 + p.hop, *x3 = x2 + p.hop;
 #pragma unroll
         for (int a = 0; a < 16; ++a) {
-          re[brev4(a)] = ld<In>(x0, 32 * a) * win[a];
-          im[brev4(a)] = ld<In>(x1, 32 * a) * win[a];
-          re[16 + brev4(a)] = ld<In>(x2, 32 * a) * win[a];
-          im[16 + brev4(a)] = ld<In>(x3, 32 * a) * win[a];
+          const float v0 = ld<In>(x0, 32 * a), v1 = ld<In>(x1, 32 * a), v2 = ld<In>(x2, 32 * a), v3 = ld<In>(x3, 32 * a);
+          if constexpr (TABLE)
+            loudest = __builtin_fmaxf(loudest, __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(v0), __builtin_fabsf(v1)),
+                                                               __builtin_fmaxf(__builtin_fabsf(v2), __builtin_fabsf(v3))));
+          re[brev4(a)] = v0 * win[a];
+          im[brev4(a)] = v1 * win[a];
+          re[16 + brev4(a)] = v2 * win[a];
+          im[16 + brev4(a)] = v3 * win[a];
         }
+      }
+      if constexpr (TABLE) {  // an asymmetric table: see StftParams::loud_flags
+        if (p.loud_flags) mark_loud(p, loudest > p.loud_thr_raw, p.frame0 + unit * 8, 8);
       }
     }
     transform512<TABLE>(re, im, tw_lds, tw_flat, plane, l);
@@ -549,6 +559,9 @@ __global__ __launch_bounds__(kWaves * 64) void stft512_rgba_kernel(StftParams p,
     // wave-uniform: does this wavefront have a frame in this iteration?
     const bool active = it < rounds * kRIters && rg.f_lo + 128 * it + 8 * wave < p.nframes;
     if (active) {
+      if constexpr (TABLE) {  // an asymmetric table: see StftParams::loud_flags
+        if (p.loud_flags) mark_loud(p, max_abs(raw) > p.loud_thr_raw, p.frame0 + rg.f_lo + 128 * it + 8 * wave, 8);
+      }
       float re[32], im[32];
       {
         float win[16];
@@ -709,6 +722,7 @@ int launch_stft_fast512(const StftParams& p, void* stream_v) {
 #undef SONO_R512_H
 #undef SONO_R512
     note_kernel(tab ? "stft512_rgba_kernel<table>" : "stft512_rgba_kernel<roots>");
+    note_marking(tab && p.loud_flags != nullptr);
     return hipGetLastError() == hipSuccess ? SONO_OK : SONO_ERR_DEVICE;
   }
 #define SONO_L512(PL, In, FE, H, T)                                                                              \
@@ -732,6 +746,7 @@ int launch_stft_fast512(const StftParams& p, void* stream_v) {
 #undef SONO_L512_F
 #undef SONO_L512
   note_kernel(tab ? "stft512_kernel<table>" : "stft512_kernel<roots>");
+  note_marking(tab && p.out_kind == SONO_OUT_U8_INDEX && p.loud_flags != nullptr);
   return hipGetLastError() == hipSuccess ? SONO_OK : SONO_ERR_DEVICE;
 }
 

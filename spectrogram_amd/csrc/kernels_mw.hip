@@ -140,7 +140,34 @@ __global__ __launch_bounds__((1 << LOG2N) / 16 * G, 4) void stft_mw_kernel(StftP
   for (int a1 = 0; a1 < 16; ++a1) win[rev4(a1)] = p.window[t + TN * a1];
 
   const uint64_t npairs = SINGLE ? p.nframes : (p.nframes + 1) >> 1;  // transforms
-  for (uint64_t base = (uint64_t)blockIdx.x * G; base < npairs; base += (uint64_t)gridDim.x * G) {
+  // The launch behind a kernel that pairs or splits frames (p.loud_only): only marked units are transformed.  Every
+  // wavefront looks at the marks of its next 64 iterations at once (lane j at iteration j from here) and jumps to the
+  // first one that holds a marked frame of its own; the wavefronts of a transform wider than one wavefront own the
+  // same single frame and so take the same jumps.
+  constexpr int kPerWave = TN >= 64 ? 1 : 64 / TN;  // frames (groups) per wavefront
+  auto next_marked = [&](uint64_t base) -> uint64_t {
+    if constexpr (SINGLE && OUT == kOutU8) {
+      if (p.loud_only) {
+        const uint64_t step = (uint64_t)gridDim.x * G;
+        const uint64_t mine = TN >= 64 ? 0 : (uint64_t)(threadIdx.x >> 6) * kPerWave;  // this wavefront's first frame in an iteration
+        while (base < npairs) {
+          const uint64_t b = base + (uint64_t)(threadIdx.x & 63) * step;
+          bool m = false;
+          if (b + mine < npairs) {
+            const uint64_t fr = p.frame0 + b + mine;
+            m = p.loud_flags[(fr >> 2) & p.loud_mask] != 0;
+            if (kPerWave > 1 && b + mine + kPerWave - 1 < npairs) m = m || p.loud_flags[((fr + kPerWave - 1) >> 2) & p.loud_mask] != 0;
+          }
+          const uint64_t hit = __builtin_amdgcn_ballot_w64(m);
+          if (hit) return base + (uint64_t)__builtin_ctzll(hit) * step;
+          base += 64 * step;
+        }
+        return npairs;
+      }
+    }
+    return base;
+  };
+  for (uint64_t base = next_marked((uint64_t)blockIdx.x * G); base < npairs; base = next_marked(base + (uint64_t)gridDim.x * G)) {
     // every group of the workgroup goes through every iteration (the larger sizes meet at barriers); one
     // without a pair of its own repeats the last pair and stores nothing
     const bool active = base + grp < npairs;
@@ -150,17 +177,6 @@ __global__ __launch_bounds__((1 << LOG2N) / 16 * G, 4) void stft_mw_kernel(StftP
     if (!SINGLE && f0 + 1 >= p.nframes) {  // odd last frame: computed as the second member of the pair before it
       f0 -= 1;
       st_a = false;
-    }
-    if constexpr (SINGLE && OUT == kOutU8) {
-      // the second launch behind a kernel that pairs frames (or splits them): only the units it marked
-      // (StftParams::loud_flags).  The test is made per wavefront, for every frame its groups hold, so that the lanes of
-      // a wavefront stay together; a workgroup of several wavefronts per transform holds one frame, so it is uniform there.
-      if (p.loud_only) {
-        constexpr int kPerWave = TN >= 64 ? 1 : 64 / TN;
-        const uint64_t first = TN >= 64 ? base + grp : base + (threadIdx.x >> 6) * kPerWave;
-        const uint64_t last = first + kPerWave - 1 < p.nframes ? first + kPerWave - 1 : p.nframes - 1;
-        if (first >= p.nframes || !is_loud(p, p.frame0 + first, (uint32_t)(last - first + 1))) continue;
-      }
     }
     const In* xa = x + (p.frame0 + f0) * p.hop + t;
     float re[16], im[16];
@@ -253,7 +269,7 @@ __global__ __launch_bounds__((1 << LOG2N) / 16 * G, 4) void stft_mw_kernel(StftP
 #pragma unroll
     for (int m = 0; m < (N / 8) / TN; ++m) {
       const int k = 4 * (t + TN * m);
-      if (BANK || (k + 3 >= (int)p.bin_lo && k < (int)p.bin_hi)) {  // (BANK: a tap may lie outside the band; an image's band may cut a quad)
+      if (BANK || (k >= (int)p.bin_lo && k < (int)p.bin_hi)) {  // (BANK: a tap may lie outside the band)
         uint32_t wa = 0, wb = 0;
         float fa[4] = {0, 0, 0, 0}, fb[4] = {0, 0, 0, 0};
         const int cellZ = k + (k >> 5);  // + B (k is a multiple of 4)
@@ -303,12 +319,8 @@ __global__ __launch_bounds__((1 << LOG2N) / 16 * G, 4) void stft_mw_kernel(StftP
           if (st_a) *reinterpret_cast<float4*>(o + row_a) = make_float4(fa[0], fa[1], fa[2], fa[3]);
           if (!SINGLE && active) *reinterpret_cast<float4*>(o + row_b) = make_float4(fb[0], fb[1], fb[2], fb[3]);
         } else if constexpr (!FEAT) {
-          if (SINGLE && p.out_kind == SONO_OUT_RGBA8) {  // the second launch behind an image writer: the frame's column
-            if (st_a) store_column_pixels(p, f0, k, wa);
-          } else {
-            if (st_a) *reinterpret_cast<uint32_t*>(out + row_a + col) = wa;
-            if (!SINGLE && active) *reinterpret_cast<uint32_t*>(out + row_b + col) = wb;
-          }
+          if (st_a) *reinterpret_cast<uint32_t*>(out + row_a + col) = wa;
+          if (!SINGLE && active) *reinterpret_cast<uint32_t*>(out + row_b + col) = wb;
         }
       }
     }
@@ -419,16 +431,15 @@ bool mw_u8_available(const StftParams& p) {
 
 int launch_stft_mw(const StftParams& p, void* stream_v) {
   using namespace mw;
-  // the second launch behind a kernel that pairs or splits frames: one frame per transform, marked units only, colour
-  // indices into rows or -- behind an image writer -- pixels into the frames' image columns
-  const bool marked = p.loud_only && p.loud_flags && !p.fb_packed &&
-                      (p.out_kind == SONO_OUT_U8_INDEX || (p.out_kind == SONO_OUT_RGBA8 && p.lut));
-  const bool u8 = p.out_kind == SONO_OUT_U8_INDEX || marked, feat = p.out_kind == SONO_OUT_FEATURES;
+  // the second launch behind a kernel that pairs or splits frames: one frame per transform, marked units only
+  const bool marked = p.loud_only && p.loud_flags && !p.fb_packed && p.out_kind == SONO_OUT_U8_INDEX;
+  const bool u8 = p.out_kind == SONO_OUT_U8_INDEX, feat = p.out_kind == SONO_OUT_FEATURES;
   const bool flt = p.out_kind == SONO_OUT_F32_DB || p.out_kind == SONO_OUT_F32_MAG;
   if (!(u8 || feat || flt)) return 1;
   // one frame per transform where two would not do: float32 outputs under an asymmetric table (StftParams::pair_exact),
   // colour indices under a table whose cross-talk could show (StftParams::pair_idx_ok)
-  const bool single = (flt && !p.pair_exact) || (u8 && !p.pair_idx_ok) || marked;
+  // (this kernel's pairing flavour marks nothing: where the caller relies on marks it transforms one frame at a time)
+  const bool single = (flt && !p.pair_exact) || (u8 && (!p.pair_idx_ok || p.loud_flags)) || marked;
   // a non-linear frequency scale: colour indices only, plugin quantiser
   const bool bank = p.fb_packed != nullptr;
   if (bank && (!u8 || p.scale_mode != SONO_SCALE_PLUGIN_DB)) return 1;
@@ -436,8 +447,6 @@ int launch_stft_mw(const StftParams& p, void* stream_v) {
     if ((p.n != 512 && p.n != 2048 && p.n != 4096) || !p.mw_ok || !p.twiddles || (p.bin_lo & 3) || (p.bin_hi & 3) ||
         p.bin_lo >= p.bin_hi || p.nframes < 2)
       return 1;
-  } else if (marked && p.out_kind == SONO_OUT_RGBA8) {  // (an image's band need not be whole groups of four bins)
-    if ((p.n != 512 && p.n != 2048 && p.n != 4096) || !p.mw_ok || !p.twiddles || p.nframes < 1) return 1;
   } else if (!mw_u8_available(p)) {
     return 1;
   }

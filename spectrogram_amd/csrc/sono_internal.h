@@ -125,6 +125,10 @@ int launch_resample(const uint8_t* in, uint64_t in_frames, uint32_t bins, uint64
                     uint8_t* out, void* hip_stream);
 int launch_colorize(const uint8_t* frames, uint64_t ncols, uint32_t bins, uint32_t row0, uint32_t rows,
                     const uint32_t* lut, uint8_t* rgba, uint64_t img_width, uint64_t col0, void* hip_stream);
+// kernels_post.hip: the image columns of the marked frames of a chunk (StftParams::loud_flags) from their colour indices.
+int launch_colorize_marked(const uint8_t* frames, uint64_t ncols, uint32_t bins, uint32_t bin_first, uint32_t band_lo, uint32_t band_hi,
+                           int32_t row_of_bin0, const uint32_t* lut, uint8_t* rgba, uint64_t img_width, uint64_t col0,
+                           const uint8_t* flags, uint32_t mask, uint64_t frame_base, void* hip_stream);
 int launch_canvas_draw(const uint8_t* frames, uint64_t width, uint32_t bins, int64_t sy, int64_t sh, double dy, double dh,
                        uint32_t height, uint32_t background, const uint32_t* lut, uint8_t* canvas, void* hip_stream);
 // True when launch_stft_fast has a kernel for this size / layout with uint8 output.

@@ -38,17 +38,5 @@ __device__ __forceinline__ bool is_loud(const StftParams& p, uint64_t frame, uin
   return any;
 }
 
-// Second launch into an image: the colour indices of four consecutive bins k .. k+3 (byte B = bin k + B) of one frame as
-// four pixels of the frame's image column (image row of bin y: row_of_bin0 - y), bins outside the band left alone.
-__device__ __forceinline__ void store_column_pixels(const StftParams& p, uint64_t frame_in_launch, int k, uint32_t w) {
-  uint32_t* img = reinterpret_cast<uint32_t*>(p.out);
-#pragma unroll
-  for (int B = 0; B < 4; ++B) {
-    const int y = k + B;
-    if (y < (int)p.bin_lo || y >= (int)p.bin_hi) continue;
-    img[(int64_t)(p.row_of_bin0 - y) * (int64_t)p.width + (int64_t)(p.col0 + frame_in_launch)] = p.lut[(w >> (8 * B)) & 255u];
-  }
-}
-
 }  // namespace sono
 #endif

@@ -108,7 +108,7 @@ def test_fft4096_kernel_indices_and_image(hop, in_kind, round_frames, monkeypatc
             route = eng.kernel_route()
         want = lut.reshape(256, 4)[got[:, lo:hi].T[::-1]]
         if hop % 4 == 0:
-            assert route == "stft4096_kernel<image>:rgba + stft_mw_kernel<4096,single,marked>", route
+            assert route == "stft4096_kernel<image>:rgba + stft_mw_kernel<4096,single,marked> + colorize_marked_kernel", route
             assert img.shape == want.shape and np.array_equal(img, want)          # same arithmetic, same indices
         else:
             assert route == "stft_mw_kernel<4096,single>:u8 + colorize_kernel", route

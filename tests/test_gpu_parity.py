@@ -255,8 +255,8 @@ def test_colour_indices_within_one_lsb_under_near_full_scale_tones(n):
     the display range.  Transformed two frames at a time (or, at 4096 points, as even and odd samples) under the
     plugin's recurrence factors, such frames came out 2 LSB off the reference in about one pixel in 10^5 -- the bins
     within a few dB of the -100 dB floor that sit where the table's Hermitian defect puts the tone's image.  With the
-    loud units marked and recomputed (1024, 4096 points) or every frame transformed alone (512, 2048 points) every
-    pixel is within 1 LSB, for random tone frequencies, phases, levels and floors."""
+    loud units marked and recomputed one frame per transform every pixel is within 1 LSB, for random tone frequencies,
+    phases, levels and floors."""
     hop = n // 4
     rng = np.random.default_rng(n + 1)
     L = n + hop * 31 + 1
@@ -271,8 +271,10 @@ def test_colour_indices_within_one_lsb_under_near_full_scale_tones(n):
             d = cyc_diff(eng.stft(x), ref)
             assert d.max() <= 1 and (d != 0).mean() < 0.02, (n, trial, f, amp, noise, int((d > 1).sum()))
         route = eng.kernel_route()
-    assert route == {512: "stft_mw_kernel<512,single>", 1024: "stft1024_u8_kernel<table> + stft1024_u8_kernel<table,single,marked>",
-                     2048: "stft_mw_kernel<2048,single>", 4096: "stft4096_kernel + stft_mw_kernel<4096,single,marked>"}[n], route
+    assert route == {512: "stft512_kernel<table> + stft_mw_kernel<512,single,marked>",
+                     1024: "stft1024_u8_kernel<table> + stft1024_u8_kernel<table,single,marked>",
+                     2048: "stft2048_kernel<table> + stft_mw_kernel<2048,single,marked>",
+                     4096: "stft4096_kernel + stft_mw_kernel<4096,single,marked>"}[n], route
 
 
 def test_plugin_accurate_twiddles_differ_from_recurrence_at_4096():
@@ -451,8 +453,9 @@ def test_kernel_route_is_visible_and_default_view_is_fast():
         assert eng.kernel_route() == ""
         eng.set_colormap(lut)
         img = eng.stft(x)
-        # (+ the launch that recomputes, one frame per transform, the units the image writer marked as loud)
-        assert eng.kernel_route() == "stft1024_rgba_kernel<table>:rgba + stft1024_u8_kernel<table,single,marked>"
+        # (+ the launches that recompute, one frame per transform, the units the image writer marked as loud and write
+        # their columns)
+        assert eng.kernel_route() == "stft1024_rgba_kernel<table>:rgba + stft1024_u8_kernel<table,single,marked> + colorize_marked_kernel"
     want = ref[:, lo:hi].T[::-1].astype(np.int16)
     l4 = lut.reshape(256, 4)
     ok = np.zeros(want.shape, bool)
@@ -467,7 +470,7 @@ def test_kernel_route_is_visible_and_default_view_is_fast():
         assert eng.kernel_route() == "stft1024_rgba_kernel<roots>:rgba + stft_general_kernel<float>"   # + the wrapped last frame
     with plugin_engine(4096, 256, F.ARITH_FAST_F32, out_kind=F.OUT_RGBA8, bin_lo=160, bin_hi=1280) as eng:
         eng.stft(x)
-        assert eng.kernel_route() == "stft4096_kernel<image>:rgba + stft_mw_kernel<4096,single,marked>"
+        assert eng.kernel_route() == "stft4096_kernel<image>:rgba + stft_mw_kernel<4096,single,marked> + colorize_marked_kernel"
     with plugin_engine(256, 64, F.ARITH_FAST_F32) as eng:
         eng.stft(x)
         assert eng.kernel_route() == "stft_general_kernel<float>"
@@ -483,8 +486,7 @@ def test_one_frame_per_transform_where_pairing_would_leak():
     At the default gain / range that could move a colour index near the -100 dB floor by more than a step once samples
     exceed a few hundredths of full scale, so the 1024-point kernel marks the loud units and a second launch recomputes
     them with one real frame per transform, whose spectrum is the reference's own transform of that frame; a display
-    floor the defect cannot reach keeps the pairs alone; float32 dB output has no floor at all and never pairs; the
-    sizes whose kernels do not mark transform one frame at a time throughout."""
+    floor the defect cannot reach keeps the pairs alone; float32 dB output has no floor at all and never pairs."""
     rng = np.random.default_rng(1024)
     L = 1024 + 256 * 700 + 3
     x = (rng.standard_normal(L) * 1e-4).astype(np.float32)
@@ -509,12 +511,13 @@ def test_one_frame_per_transform_where_pairing_would_leak():
     want = 20.0 * np.log10(np.maximum(mags.astype(np.float64), 1e-12))
     near = mags > mags.max(axis=1, keepdims=True) * 10 ** (-75 / 20)
     assert np.abs(db - want)[near].max() <= 0.01
-    # the other sizes: the three-pass kernel has the same flavour (2048 points, rectangular window; float32 dB at 512)
+    # the other sizes: the register kernels mark as well and the three-pass kernel recomputes (2048 points, rectangular
+    # window); float32 dB comes from its one-frame-per-transform flavour (512 points)
     y = x[:2048 + 512 * 300 + 1]
     ref = oracle.plugin_get_frequencies(y, 2048, 1536, window="rectangular")
     with plugin_engine(2048, 512, F.ARITH_FAST_F32, window="rectangular") as eng:
         got = eng.stft(y)
-        assert eng.kernel_route() == "stft_mw_kernel<2048,single>"
+        assert eng.kernel_route() == "stft2048_kernel<table> + stft_mw_kernel<2048,single,marked>"
     assert got.shape == ref.shape and cyc_diff(got, ref).max() <= 1 and (got == ref).mean() > 0.98
     _, mags, _, _ = oracle.plugin_get_frequencies(y, 512, 384, want_mags=True)
     with plugin_engine(512, 128, F.ARITH_FAST_F32, out_kind=F.OUT_F32_DB) as eng:
