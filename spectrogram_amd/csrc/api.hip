@@ -555,11 +555,13 @@ static int refresh_routes(sono_ctx* c) {
       c->split_ok = !marks;
     }
     const bool index_out = c->cfg.out_kind == SONO_OUT_U8_INDEX || c->cfg.out_kind == SONO_OUT_RGBA8;
-    if (marks && index_out && thr_raw >= 0.02 && !c->d_fb_bin && c->cfg.arith == SONO_ARITH_FAST_F32) {
+    // (a filter bank: the 1024-point kernel alone applies it to pairs; the 1024-point kernels redo their loud units
+    // themselves and need no marks)
+    if (marks && index_out && thr_raw >= 0.02 && (!c->d_fb_bin || n == 1024) && c->cfg.arith == SONO_ARITH_FAST_F32) {
       c->loud_marks = true;
       c->loud_thr_raw = (float)thr_raw;
       c->loud_thr_win = (float)thr_win;
-      if (!c->d_loud) HIP_TRY(c, hipMalloc((void**)&c->d_loud, kLoudFlagBytes));
+      if (n != 1024 && n != 2048 && !c->d_loud) HIP_TRY(c, hipMalloc((void**)&c->d_loud, kLoudFlagBytes));
     }
     // (the 4096-point kernel without marks would be unsafe: see launch_range)
   }
@@ -612,11 +614,14 @@ static int launch_range(sono_ctx* c, const StftParams& q_in, const IndexScratch&
   StftParams q = q_in;
   // An asymmetric table whose pairs (1024 points) or split frames (4096 points) are safe only below a sample level: the
   // kernels mark the loud units and a one-frame-per-transform launch recomputes them (refresh_routes).
-  const bool loud = c->loud_marks && c->d_loud && !exact && !q_in.fb_bin && q_in.nframes >= 16 &&
-                    (q_in.out_kind == SONO_OUT_U8_INDEX || rgba);
+  const bool loud = c->loud_marks && (c->d_loud || q_in.n == 1024 || q_in.n == 2048) && !exact && q_in.nframes >= 16 &&
+                    (q_in.out_kind == SONO_OUT_U8_INDEX || rgba) &&
+                    (!q_in.fb_bin || (q_in.n == 1024 && fb_fused && fb_1024));  // (a filter bank: the 1024-point kernel alone)
   if (loud) {
-    q.loud_flags = c->d_loud;
-    q.loud_mask = (uint32_t)(kLoudFlagBytes - 1);
+    if (q.n != 1024 && q.n != 2048) {  // (the 1024- and 2048-point kernels transform their loud units once more themselves)
+      q.loud_flags = c->d_loud;
+      q.loud_mask = (uint32_t)(kLoudFlagBytes - 1);
+    }
     q.loud_thr_raw = c->loud_thr_raw;
     q.loud_thr_win = c->loud_thr_win;
     if (q.n != 4096) q.pair_idx_ok = 1;  // (4096 points: the pairing three-pass kernel stays off, the splitting kernel marks)
@@ -642,7 +647,7 @@ static int launch_range(sono_ctx* c, const StftParams& q_in, const IndexScratch&
     if (!u.loud_flags || !t_marks) return SONO_OK;  // (a kernel that transforms one frame at a time marks nothing)
     StftParams s2 = u;
     s2.loud_only = 1;
-    int r2 = s2.n == 1024 ? launch_stft_fast_loud(s2, c->stream) : launch_stft_mw(s2, c->stream);
+    int r2 = launch_stft_mw(s2, c->stream);
     if (r2 != SONO_OK) return fail(c, r2 < 0 ? r2 : SONO_ERR_DEVICE, "launch of the pass over the marked frames failed");
     note_route(c);
     return SONO_OK;
@@ -690,7 +695,7 @@ static int launch_range(sono_ctx* c, const StftParams& q_in, const IndexScratch&
         u.frame0 = q.frame0 + f;
         u.nframes = (q.nframes - f < chunk + 64) ? q.nframes - f : chunk;
         u.col0 = 0;
-        int r2 = u.n == 1024 ? launch_stft_fast_loud(u, c->stream) : launch_stft_mw(u, c->stream);
+        int r2 = launch_stft_mw(u, c->stream);
         if (r2 != SONO_OK) return fail(c, r2 < 0 ? r2 : SONO_ERR_DEVICE, "launch of the pass over the marked frames failed");
         note_route(c);
         r2 = launch_colorize_marked((const uint8_t*)c->d_aux, u.nframes, (uint32_t)nb, u.bin_lo, q.bin_lo, q.bin_hi, q.row_of_bin0,

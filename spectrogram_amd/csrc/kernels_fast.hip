@@ -25,6 +25,7 @@
 
 #include <cmath>
 #include <cstdlib>
+#include <type_traits>
 #include <vector>
 
 #include "sono_device.h"
@@ -70,6 +71,9 @@ __global__ __launch_bounds__(kMaxWaves * 64, 4) void stft1024_u8_kernel(StftPara
                                                                         const float2* __restrict__ tw_table) {
   constexpr bool FEAT = OUT == kOutFeatures, FLT = OUT == kOutDb || OUT == kOutMag;
   constexpr bool SINGLE = HOP32 < 0, BANK = OUT == kOutU8Bank;
+  // Flavours that pair frames under the context's table redo a unit that is too loud for the pair separation under that
+  // table (StftParams::loud_thr_raw) themselves: two more passes of the loop body, frame A alone and frame B alone.
+  constexpr bool REDO = TABLE && !SINGLE && (OUT == kOutU8 || BANK);
   static_assert(!(SINGLE && FEAT), "the feature records come from the paired flavour (its marks cover the cross-talk)");
   constexpr int kThreads = kMaxWaves * 64, kWaves = kMaxWaves;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -117,14 +121,12 @@ __global__ __launch_bounds__(kMaxWaves * 64, 4) void stft1024_u8_kernel(StftPara
   // second member of the pair before it.  `active` is false when the wavefront has no frame left.
   struct Unit {
     uint64_t f0;
-    uint64_t w0;  // the wavefront's first frame (wave-uniform)
     bool active, st_a, st_b;
   };
   auto locate = [&](uint64_t it) -> Unit {
     Unit u;
     const uint64_t pair0 = (((uint64_t)vb * iters + it) * kWaves + wave) * 2;
     u.active = it < iters && pair0 < npairs;  // wave-uniform
-    u.w0 = SINGLE ? pair0 : 2 * pair0;
     if (!u.active) {            // nothing left: point at frame 0 so that the sample loads stay in bounds
       u.f0 = 0;
       u.st_a = u.st_b = false;
@@ -151,11 +153,16 @@ __global__ __launch_bounds__(kMaxWaves * 64, 4) void stft1024_u8_kernel(StftPara
   // arithmetic.
   constexpr int kRaw = SINGLE ? 32 : HOP32 > 0 ? 32 + HOP32 : 64;
   float raw[kRaw];
-  auto fetch = [&](const Unit& u) {
+  // (alone: frame u.f0 only -- the frame after it may lie beyond the signal)
+  auto fetch = [&](const Unit& u, bool alone) {
     const In* xa = x + (p.frame0 + u.f0) * p.hop + l;
-    if constexpr (SINGLE) {
+    if (SINGLE || alone) {
+      // (opaque: or the samples already loaded for the pair are kept in registers instead of being read again)
+      if constexpr (!SINGLE) asm volatile("" : "+v"(xa));
 #pragma unroll
       for (int a = 0; a < 32; ++a) raw[a] = ld<In>(xa, 32 * a);
+#pragma unroll
+      for (int a = 32; a < kRaw; ++a) raw[a] = 0.0f;  // (defined, so that nothing is carried round the loop)
     } else if constexpr (HOP32 > 0) {
 #pragma unroll
       for (int a = 0; a < 32 + HOP32; ++a) raw[a] = ld<In>(xa, 32 * a);
@@ -168,41 +175,29 @@ __global__ __launch_bounds__(kMaxWaves * 64, 4) void stft1024_u8_kernel(StftPara
       }
     }
   };
-  // The launch behind a kernel that pairs frames (p.loud_only): only the units it marked are transformed.  A wavefront
-  // looks at the marks of its next 64 units at once (lane j at unit it + j), so the unmarked stretches cost one load
-  // per 64 units and no sample is fetched for them.
-  auto next_marked = [&](uint64_t it) -> uint64_t {
-    if constexpr (SINGLE && OUT == kOutU8) {
-      if (p.loud_only) {
-        while (it < iters) {
-          const uint64_t j = it + lane;
-          const uint64_t fr = p.frame0 + (((uint64_t)vb * iters + j) * kWaves + wave) * 2;  // the unit's frames: fr, fr + 1
-          bool m = false;
-          if (j < iters && fr - p.frame0 < npairs)
-            m = (p.loud_flags[(fr >> 2) & p.loud_mask] | p.loud_flags[((fr + 1) >> 2) & p.loud_mask]) != 0;
-          const uint64_t b = __builtin_amdgcn_ballot_w64(m);
-          if (b) return it + (uint64_t)__builtin_ctzll(b);
-          it += 64;
-        }
-        return iters;
-      }
-    }
-    return it;
-  };
-  uint64_t it = next_marked(0);
+  uint64_t it = 0;
   Unit cur = locate(it);
-  fetch(cur);
+  fetch(cur, false);
+  int mode = 0;  // REDO: 0 = the pair (A, B) in one transform; 1 / 2 = frame A / frame B alone.  Wave-uniform.
   while (cur.active) {
-    const uint64_t it_next = next_marked(it + 1);
-    const Unit nxt = locate(it_next);
-    it = it_next;
-    const uint64_t f0 = cur.f0;
-    const bool st_a = cur.st_a, st_b = SINGLE ? false : cur.st_b;
-#ifndef SONO_EXP_NOMARK
-    if constexpr (TABLE && !SINGLE && (OUT == kOutU8)) {
-      if (p.loud_flags) mark_loud(p, max_abs(raw) > p.loud_thr_raw, p.frame0 + cur.w0, 4);
+    const uint64_t f0 = cur.f0;  // the frame whose row the first result goes to
+    const bool st_a = cur.st_a;
+    bool st_b = SINGLE ? false : cur.st_b;
+    if constexpr (REDO) {
+      // the four frames of a wavefront are redone together (its two halves run in lockstep anyway); a NaN sample does
+      // not compare as loud and needs no second look (it poisons every bin either way)
+      if (mode == 0 && p.loud_thr_raw > 0.0f && __builtin_amdgcn_ballot_w64(max_abs(raw) > p.loud_thr_raw) != 0) mode = 1;
     }
-#endif
+    const uint64_t it_next = (REDO && mode == 1) ? it : it + 1;
+    Unit nxt = locate(it_next);
+    it = it_next;
+    if constexpr (REDO) {
+      if (mode == 1) {  // frame A alone now; then this unit once more as "frame B alone" (its samples come from the cache)
+        nxt.f0 = f0 + 1;
+        nxt.st_a = st_b;
+      }
+      if (mode != 0) st_b = false;
+    }
 
     float re[32], im[32];
     {
@@ -216,6 +211,10 @@ __global__ __launch_bounds__(kMaxWaves * 64, 4) void stft1024_u8_kernel(StftPara
       for (int a = 0; a < 32; ++a) {
         re[brev5(a)] = raw[a] * win[a];
         im[brev5(a)] = SINGLE ? 0.0f : raw[SINGLE ? a : a + (HOP32 > 0 ? HOP32 : 32)] * win[a];
+      }
+      if (REDO && mode != 0) {
+#pragma unroll
+        for (int a = 0; a < 32; ++a) im[a] = 0.0f;
       }
     }
     // first pass; then (exact roots only) the twiddle W_1024^(l*k1); then transpose lane l, register
@@ -293,6 +292,11 @@ __global__ __launch_bounds__(kMaxWaves * 64, 4) void stft1024_u8_kernel(StftPara
     // (FEAT: an opaque copy keeps the loop-invariant bin numbers and band tests out of registers the transform needs;
     // hoisted, they were spilled and every reload waited on the memory counter)
     if constexpr (FEAT) asm volatile("" : "+v"(lq));
+    // ALONE (REDO flavours, mode 1 / 2): the transform held one frame; its spectrum is Z itself, taken twice so that the
+    // quantiser sees the same factor 2 as the pair separation leaves, and there is no second result.
+    auto epilogue = [&](auto alone_c) __attribute__((always_inline)) {
+    constexpr bool ALONE = decltype(alone_c)::value;
+    constexpr bool S = SINGLE || ALONE;  // no partner to read
 #pragma unroll
     for (int P = 0; P < 2; ++P) {
 #pragma unroll
@@ -300,9 +304,9 @@ __global__ __launch_bounds__(kMaxWaves * 64, 4) void stft1024_u8_kernel(StftPara
         const int kl = 8 * P + r;        // Z[k1 + 32*kl]        -> lbuf[32*r + k1]
         const int km = 24 - 8 * P + r;   // Z[k1 + 32*km] = Z[N - j], j = 32*(7 - r) + 32 - k1 (+256P)
         lbuf[32 * r + l] = make_float2(re[kl], im[kl]);
-        if constexpr (!SINGLE) mbuf[32 * (7 - r) + 32 - l] = make_float2(re[km], im[km]);
+        if constexpr (!S) mbuf[32 * (7 - r) + 32 - l] = make_float2(re[km], im[km]);
       }
-      if constexpr (!SINGLE) {
+      if constexpr (!S) {
         if (l == 0) mbuf[0] = make_float2(re[P ? 24 : 0], im[P ? 24 : 0]);
       }
       wave_sync();
@@ -312,14 +316,15 @@ __global__ __launch_bounds__(kMaxWaves * 64, 4) void stft1024_u8_kernel(StftPara
         const int k = 256 * P + idx;
         const float4 z01 = *reinterpret_cast<const float4*>(lbuf + idx);
         const float4 z23 = *reinterpret_cast<const float4*>(lbuf + idx + 2);
-        const float4 q01 = SINGLE ? make_float4(0, 0, 0, 0) : *reinterpret_cast<const float4*>(mbuf + idx);
-        const float4 q23 = SINGLE ? make_float4(0, 0, 0, 0) : *reinterpret_cast<const float4*>(mbuf + idx + 2);
+        const float4 q01 = S ? make_float4(0, 0, 0, 0) : *reinterpret_cast<const float4*>(mbuf + idx);
+        const float4 q23 = S ? make_float4(0, 0, 0, 0) : *reinterpret_cast<const float4*>(mbuf + idx + 2);
         uint32_t wa = 0, wb = 0;
         float fa[4] = {0, 0, 0, 0}, fb[4] = {0, 0, 0, 0};
         const bool in_band = k >= (int)p.bin_lo && k < (int)p.bin_hi;
 #define SONO_BIN(B, ZR, ZI, PR, PI)                                          \
   {                                                                          \
-    const float ar = SINGLE ? (ZR) : (ZR) + (PR), ai = SINGLE ? (ZI) : (ZI) - (PI); \
+    const float ar = ALONE ? (ZR) + (ZR) : SINGLE ? (ZR) : (ZR) + (PR);      \
+    const float ai = ALONE ? (ZI) + (ZI) : SINGLE ? (ZI) : (ZI) - (PI);      \
     const float br = (ZI) + (PI), bi = (PR) - (ZR);                          \
     const float ma = __builtin_fmaf(ar, ar, ai * ai);                        \
     const float mb = __builtin_fmaf(br, br, bi * bi);                        \
@@ -372,6 +377,9 @@ __global__ __launch_bounds__(kMaxWaves * 64, 4) void stft1024_u8_kernel(StftPara
       }
       wave_sync();  // the buffer is rewritten by the next half / the next iteration's transpose
     }
+    };  // epilogue
+    if (REDO && mode != 0) epilogue(std::true_type{});
+    else epilogue(std::false_type{});
     if constexpr (BANK) {
       // Both frames' magnitudes go to this half-wavefront's buffer (free between the epilogue and the next transpose),
       // each followed by a zero that a tap at the last bin reads as its neighbour; then every lane gathers the two taps
@@ -470,7 +478,8 @@ __global__ __launch_bounds__(kMaxWaves * 64, 4) void stft1024_u8_kernel(StftPara
         }
       }
     }
-    fetch(nxt);  // unconditional (an inactive unit points at frame 0): no stale values carried round the loop
+    if constexpr (REDO) mode = mode == 1 ? 2 : 0;
+    fetch(nxt, REDO && mode == 2);  // unconditional (an inactive unit points at frame 0): no stale values carried round the loop
     cur = nxt;
   }
 }
@@ -527,38 +536,6 @@ bool fast_rgba_available(const StftParams& p) {
 // Scratch of the image writers that exchange colour indices through global memory (2048 and 4096 points): two slots
 // per workgroup, a slot of the 2048-point kernel being 1024 bins x 256 frames.
 uint64_t fast_rgba_scratch_bytes() { return (uint64_t)device_cu_count() * 2 * 2 * rgba_flush::kRoundBytes; }
-
-// The second launch behind a 1024-point kernel that pairs frames under an asymmetric table: one frame per transform,
-// only the units marked in p.loud_flags, colour indices into [frame][bin] rows.
-int launch_stft_fast_loud(const StftParams& p, void* stream_v) {
-  using namespace fast1024;
-  if (p.n != 1024 || p.fast_mode != 2 || !p.twiddles || !p.loud_flags || !p.loud_only) return 1;
-  if (p.out_kind != SONO_OUT_U8_INDEX || !fast_u8_available(p)) return 1;
-  if (reinterpret_cast<uintptr_t>(p.out) & 3) return 1;
-  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_v);
-  FastScale fs = make_fast_scale(p.scale_mode, p.n, p.gain_db, p.range_db);
-  fs.xtalk = 0.0f;
-  const uint64_t need = (p.nframes + 2 * kMaxWaves - 1) / (2 * kMaxWaves);
-  const int cus = device_cu_count();
-  const uint32_t grid = (uint32_t)(need < (uint64_t)cus ? need : (uint64_t)cus);
-  const int lds_total = lds_bytes(kMaxWaves);
-  const float2* table = reinterpret_cast<const float2*>(p.fast_table);
-#define SONO_LAUNCH_S(PLUGIN, In)                                                                          \
-  do {                                                                                                      \
-    auto kern = stft1024_u8_kernel<PLUGIN, In, -1, kOutU8, true>;                                           \
-    SONO_GRANT_LDS(kern, lds_total);                                                                        \
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(kMaxWaves * 64), lds_total, stream, p, fs, table);            \
-  } while (0)
-  const bool plugin = p.scale_mode == SONO_SCALE_PLUGIN_DB;
-  if (p.in_kind == SONO_IN_I16) {
-    if (plugin) SONO_LAUNCH_S(true, int16_t); else SONO_LAUNCH_S(false, int16_t);
-  } else {
-    if (plugin) SONO_LAUNCH_S(true, float); else SONO_LAUNCH_S(false, float);
-  }
-#undef SONO_LAUNCH_S
-  note_kernel("stft1024_u8_kernel<table,single,marked>");
-  return hipGetLastError() == hipSuccess ? SONO_OK : SONO_ERR_DEVICE;
-}
 
 int launch_stft_fast(const StftParams& p, void* stream_v) {
   using namespace fast1024;
@@ -636,11 +613,13 @@ int launch_stft_fast(const StftParams& p, void* stream_v) {
 #undef SONO_LAUNCH_H
 #undef SONO_LAUNCH_O
 #undef SONO_LAUNCH_T
+  // (redo: a flavour that pairs frames under the table and transforms its loud units one frame at a time)
+  const bool redo = tab && !single && (bank || p.out_kind == SONO_OUT_U8_INDEX) && p.loud_thr_raw > 0.0f;
   note_kernel(single ? (bank ? "stft1024_u8_kernel<table,single,bank>" : "stft1024_u8_kernel<table,single>")
-              : bank ? (tab ? "stft1024_u8_kernel<table,bank>" : "stft1024_u8_kernel<roots,bank>")
-              : tab  ? "stft1024_u8_kernel<table>"
+              : bank ? (tab ? (redo ? "stft1024_u8_kernel<table,bank,redo>" : "stft1024_u8_kernel<table,bank>") : "stft1024_u8_kernel<roots,bank>")
+              : tab  ? (redo ? "stft1024_u8_kernel<table,redo>" : "stft1024_u8_kernel<table>")
                      : "stft1024_u8_kernel<roots>");
-  note_marking(tab && !single && !bank && p.out_kind == SONO_OUT_U8_INDEX && p.loud_flags != nullptr);
+  note_marking(false);  // (the flavours that pair frames under a table redo their loud units themselves)
   return hipGetLastError() == hipSuccess ? SONO_OK : SONO_ERR_DEVICE;
 }
 

@@ -16,6 +16,8 @@
 // Outputs: [frame][bin] colour indices, or per-frame spectral peaks.
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include <cmath>
 #include <vector>
 
@@ -356,19 +358,34 @@ __global__ __launch_bounds__(kWaves * 64) void stft2048_kernel(StftParams p, Fas
   const uint64_t iters = ((nunits + kWaves - 1) / kWaves + gridDim.x - 1) / gridDim.x;
   const uint64_t unit_end = ((uint64_t)vb + 1) * iters * kWaves < nunits ? ((uint64_t)vb + 1) * iters * kWaves : nunits;
 
-  for (uint64_t unit = (uint64_t)vb * iters * kWaves + wave; unit < unit_end; unit += kWaves) {
+  // REDO: under the context's table a pair too loud for the pair separation (StftParams::loud_thr_raw) is transformed one
+  // frame at a time: the loop body runs twice more, mode 1 = frame fb alone, mode 2 = frame fb + 1 alone.
+  constexpr bool REDO = TABLE && !FEAT;
+  int mode = 0;
+  for (uint64_t unit = (uint64_t)vb * iters * kWaves + wave; unit < unit_end;) {
     const uint64_t f0 = unit * 2;
     // the frames transformed are fb, fb + 1; an odd last frame is the second of the pair before it (frames before f0
     // are another wavefront's and are not stored)
     const uint64_t fb = f0 + 2 <= p.nframes ? f0 : p.nframes - 2;
     float re[32], im[32];
     {
-      const In* x0 = x + (p.frame0 + fb) * p.hop + lane;
-      float loudest = 0.0f;  // TABLE: this lane's largest |sample| (the wavefront's two frames are marked if it is loud)
+      // mode 2: frame fb + 1 alone, through the same code as a pair (its samples come from the cache; nothing behind
+      // them is read, the frame after it may lie beyond the signal)
+      const bool second = REDO && mode == 2;
+      const In* x0 = x + (p.frame0 + fb + (second ? 1 : 0)) * p.hop + lane;
+      if constexpr (REDO) asm volatile("" : "+v"(x0));  // (opaque: or samples already loaded are held in registers instead)
+      float loudest = 0.0f;  // TABLE: this lane's largest |sample|
       if constexpr (HOP64 > 0) {
         float raw[32 + HOP64];
 #pragma unroll
-        for (int a = 0; a < 32 + HOP64; ++a) raw[a] = ld<In>(x0, 64 * a);
+        for (int a = 0; a < 32; ++a) raw[a] = ld<In>(x0, 64 * a);
+        if (second) {
+#pragma unroll
+          for (int a = 32; a < 32 + HOP64; ++a) raw[a] = 0.0f;
+        } else {
+#pragma unroll
+          for (int a = 32; a < 32 + HOP64; ++a) raw[a] = ld<In>(x0, 64 * a);
+        }
         if constexpr (TABLE) loudest = max_abs(raw);
 #pragma unroll
         for (int a = 0; a < 32; ++a) {
@@ -378,17 +395,30 @@ __global__ __launch_bounds__(kWaves * 64) void stft2048_kernel(StftParams p, Fas
         }
       } else {
         const In* x1 = x0 + p.hop;
+        float v1[32];
+        if (second) {
+#pragma unroll
+          for (int a = 0; a < 32; ++a) v1[a] = 0.0f;
+        } else {
+#pragma unroll
+          for (int a = 0; a < 32; ++a) v1[a] = ld<In>(x1, 64 * a);
+        }
 #pragma unroll
         for (int a = 0; a < 32; ++a) {
           const float w = win_lds[64 * a + lane];
-          const float v0 = ld<In>(x0, 64 * a), v1 = ld<In>(x1, 64 * a);
-          if constexpr (TABLE) loudest = __builtin_fmaxf(loudest, __builtin_fmaxf(__builtin_fabsf(v0), __builtin_fabsf(v1)));
+          const float v0 = ld<In>(x0, 64 * a);
+          if constexpr (TABLE) loudest = __builtin_fmaxf(loudest, __builtin_fmaxf(__builtin_fabsf(v0), __builtin_fabsf(v1[a])));
           re[brev5(a)] = v0 * w;
-          im[brev5(a)] = v1 * w;
+          im[brev5(a)] = v1[a] * w;
         }
       }
-      if constexpr (TABLE) {  // an asymmetric table: see StftParams::loud_flags
-        if (p.loud_flags) mark_loud(p, loudest > p.loud_thr_raw, p.frame0 + f0, 2);
+      if constexpr (REDO) {
+        // (a NaN sample does not compare as loud and needs no second look: it poisons every bin either way)
+        if (mode == 0 && p.loud_thr_raw > 0.0f && __builtin_amdgcn_ballot_w64(loudest > p.loud_thr_raw) != 0) mode = 1;  // frame fb alone
+        if (mode != 0) {
+#pragma unroll
+          for (int a = 0; a < 32; ++a) im[a] = 0.0f;
+        }
       }
     }
     int lt = lane;
@@ -410,6 +440,10 @@ __global__ __launch_bounds__(kWaves * 64) void stft2048_kernel(StftParams p, Fas
     // rounding noise and the pair's cross-talk scale with; see feature_uncertain)
     const bool banded = p.bin_lo != 0 || p.bin_hi != 1024;  // wave-uniform
     float seen_a = 0.0f, seen_b = 0.0f;
+    // ALONE (REDO, mode 1 / 2): the transform held one frame; its spectrum is Z itself, taken twice so that the quantiser
+    // sees the same factor 2 as the pair separation leaves; it goes to row_a (mode 1) or row_b (mode 2).
+    auto epilogue = [&](auto alone_c) __attribute__((always_inline)) {
+    constexpr bool ALONE = decltype(alone_c)::value;
 #pragma unroll
     for (int P = 0; P < 2; ++P) {
       if constexpr (TABLE) epilogue_cells_table(P, re, im, cell, le); else epilogue_cells(P, re, im, cell, kappa);
@@ -420,14 +454,14 @@ __global__ __launch_bounds__(kWaves * 64) void stft2048_kernel(StftParams p, Fas
         const int k = 512 * P + j4;
         const float4 z01 = *reinterpret_cast<const float4*>(cell + j4);
         const float4 z23 = *reinterpret_cast<const float4*>(cell + j4 + 2);
-        const float4 q01 = *reinterpret_cast<const float4*>(cell + kMirrorBase + j4);
-        const float4 q23 = *reinterpret_cast<const float4*>(cell + kMirrorBase + j4 + 2);
+        const float4 q01 = ALONE ? make_float4(0, 0, 0, 0) : *reinterpret_cast<const float4*>(cell + kMirrorBase + j4);
+        const float4 q23 = ALONE ? make_float4(0, 0, 0, 0) : *reinterpret_cast<const float4*>(cell + kMirrorBase + j4 + 2);
         uint32_t wa = 0, wb = 0;
         float pa[4] = {0, 0, 0, 0}, pb[4] = {0, 0, 0, 0};
         const bool in_band = k >= (int)p.bin_lo && k < (int)p.bin_hi;
 #define SONO_BIN(B, ZR, ZI, PR, PI)                                          \
   {                                                                          \
-    const float ar = (ZR) + (PR), ai = (ZI) - (PI);                          \
+    const float ar = ALONE ? (ZR) + (ZR) : (ZR) + (PR), ai = ALONE ? (ZI) + (ZI) : (ZI) - (PI); \
     const float br = (ZI) + (PI), bi = (PR) - (ZR);                          \
     const float ma = __builtin_fmaf(ar, ar, ai * ai);                        \
     const float mb = __builtin_fmaf(br, br, bi * bi);                        \
@@ -462,12 +496,19 @@ __global__ __launch_bounds__(kWaves * 64) void stft2048_kernel(StftParams p, Fas
         }
         if (!FEAT && in_band) {
           const uint32_t col = k - p.out_bin0;
-          if (st_a) *reinterpret_cast<uint32_t*>(out + row_a + col) = wa;
-          if (st_b) *reinterpret_cast<uint32_t*>(out + row_b + col) = wb;
+          if constexpr (ALONE) {
+            if (mode == 1 ? st_a : st_b) *reinterpret_cast<uint32_t*>(out + (mode == 1 ? row_a : row_b) + col) = wa;
+          } else {
+            if (st_a) *reinterpret_cast<uint32_t*>(out + row_a + col) = wa;
+            if (st_b) *reinterpret_cast<uint32_t*>(out + row_b + col) = wb;
+          }
         }
       }
       wave_sync();  // the buffer is rewritten by the next half / the next iteration's transpose
     }
+    };  // epilogue
+    if (REDO && mode != 0) epilogue(std::true_type{});
+    else epilogue(std::false_type{});
     if constexpr (FEAT) {
       // larger |X|^2 wins, equal values go to the lower bin
       reduce_peak<64>(best_a, kbest_a, next_a);
@@ -495,6 +536,14 @@ __global__ __launch_bounds__(kWaves * 64) void stft2048_kernel(StftParams p, Fas
         ft[1] = r;
       }
     }
+    if constexpr (REDO) {
+      if (mode == 1) {
+        mode = 2;
+        continue;
+      }
+      mode = 0;
+    }
+    unit += kWaves;
   }
 }
 
@@ -576,25 +625,31 @@ __global__ __launch_bounds__(kWaves * 64) void stft2048_rgba_kernel(StftParams p
   // quarter j of iteration i: part and reader unit
   auto part_of = [](int i, int j) { return kFPI == 1 ? (i & 3) : i; };
   auto unit_of = [&](int i, int j) { return kFPI == 1 ? wave + 16 * (i >> 2) : wave + 16 * j; };
-  for (uint64_t it = 0; it < (rounds + 1) * kRIters; ++it) {
+  // Under the context's table a pair too loud for the pair separation (StftParams::loud_thr_raw) is transformed one frame
+  // at a time: the iteration's transform runs twice, mode 1 = the first frame alone, mode 2 = the second frame alone.
+  int mode = 0;
+  for (uint64_t it = 0; it < (rounds + 1) * kRIters;) {
     const uint64_t round = it / kRIters;
     const int i = (int)(it % kRIters);
     const uint64_t f0 = first_frame(it);
     uint32_t* slot = slots + (round & 1) * (kSlotBytes / 4);
-    // (the empty asm is a use of the loaded registers: the wait for them lands here, before the image stores)
+    if (!(TABLE && mode == 2)) {
+      // (the empty asm is a use of the loaded registers: the wait for them lands here, before the image stores)
 #pragma unroll
-    for (int a = 0; a < kRaw; ++a) asm volatile("" : "+v"(raw[a]));
-    if (round > 0) {
-      const uint64_t frame0 = ((round - 1) * gridDim.x + vb) * kRF;
-      if (frame0 < p.nframes) {
+      for (int a = 0; a < kRaw; ++a) asm volatile("" : "+v"(raw[a]));
+      if (round > 0) {
+        const uint64_t frame0 = ((round - 1) * gridDim.x + vb) * kRF;
+        if (frame0 < p.nframes) {
 #pragma unroll
-        for (int j = 0; j < kFPI; ++j)
-          rgba_flush::flush_quarter_store<kRF>(p, fq[j], p.lut, frame0, part_of(i, j), unit_of(i, j), lane);
+          for (int j = 0; j < kFPI; ++j)
+            rgba_flush::flush_quarter_store<kRF>(p, fq[j], p.lut, frame0, part_of(i, j), unit_of(i, j), lane);
+        }
       }
     }
     if (f0 < p.nframes) {  // wave-uniform
-      if constexpr (TABLE) {  // an asymmetric table: see StftParams::loud_flags
-        if (p.loud_flags) mark_loud(p, max_abs(raw) > p.loud_thr_raw, p.frame0 + f0, 2);
+      if constexpr (TABLE) {
+        // (a NaN sample does not compare as loud and needs no second look: it poisons every bin either way)
+        if (mode == 0 && p.loud_thr_raw > 0.0f && __builtin_amdgcn_ballot_w64(max_abs(raw) > p.loud_thr_raw) != 0) mode = 1;
       }
       float re[32], im[32];
 #pragma unroll
@@ -602,6 +657,10 @@ __global__ __launch_bounds__(kWaves * 64) void stft2048_rgba_kernel(StftParams p
         const float w = win_lds[64 * a + lane];
         re[brev5(a)] = raw[a] * w;
         im[brev5(a)] = raw[a + (HOP64 > 0 ? HOP64 : 32)] * w;
+      }
+      if (TABLE && mode != 0) {
+#pragma unroll
+        for (int a = 0; a < 32; ++a) im[a] = 0.0f;
       }
       int lt = lane;
       if constexpr (TABLE) asm volatile("" : "+v"(lt));  // (as in the index kernel)
@@ -612,6 +671,10 @@ __global__ __launch_bounds__(kWaves * 64) void stft2048_rgba_kernel(StftParams p
       const int kappa = (le & 31) + ((le >> 5) ? 0 : 32);
       const bool shifted = f0 + 2 > p.nframes;  // odd end: frame f0 is the second of the pair transformed
       const int fg = 8 * i + (wave >> 1);
+      // ALONE (mode 1 / 2): the transform held one frame; its spectrum is Z itself, taken twice so that the quantiser
+      // sees the same factor 2 as the pair separation leaves; it goes to the first (mode 1) or second (mode 2) word.
+      auto epilogue = [&](auto alone_c) __attribute__((always_inline)) {
+      constexpr bool ALONE = decltype(alone_c)::value;
 #pragma unroll
       for (int P = 0; P < 2; ++P) {
         if constexpr (TABLE) epilogue_cells_table(P, re, im, cell, le); else epilogue_cells(P, re, im, cell, kappa);
@@ -621,15 +684,15 @@ __global__ __launch_bounds__(kWaves * 64) void stft2048_rgba_kernel(StftParams p
           const int j4 = 4 * (le + 64 * q);
           const float4 z01 = *reinterpret_cast<const float4*>(cell + j4);
           const float4 z23 = *reinterpret_cast<const float4*>(cell + j4 + 2);
-          const float4 q01 = *reinterpret_cast<const float4*>(cell + kMirrorBase + j4);
-          const float4 q23 = *reinterpret_cast<const float4*>(cell + kMirrorBase + j4 + 2);
+          const float4 q01 = ALONE ? make_float4(0, 0, 0, 0) : *reinterpret_cast<const float4*>(cell + kMirrorBase + j4);
+          const float4 q23 = ALONE ? make_float4(0, 0, 0, 0) : *reinterpret_cast<const float4*>(cell + kMirrorBase + j4 + 2);
           uint32_t wa = 0, wb = 0;
 #define SONO_BIN(B, ZR, ZI, PR, PI)                                          \
   {                                                                          \
-    const float ar = (ZR) + (PR), ai = (ZI) - (PI);                          \
+    const float ar = ALONE ? (ZR) + (ZR) : (ZR) + (PR), ai = ALONE ? (ZI) + (ZI) : (ZI) - (PI); \
     const float br = (ZI) + (PI), bi = (PR) - (ZR);                          \
     wa = put_index<PLUGIN, B>(__builtin_fmaf(ar, ar, ai * ai), fs, wa);      \
-    wb = put_index<PLUGIN, B>(__builtin_fmaf(br, br, bi * bi), fs, wb);      \
+    if constexpr (!ALONE) wb = put_index<PLUGIN, B>(__builtin_fmaf(br, br, bi * bi), fs, wb); \
   }
           SONO_BIN(0, z01.x, z01.y, q01.x, q01.y)
           SONO_BIN(1, z01.z, z01.w, q01.z, q01.w)
@@ -637,11 +700,37 @@ __global__ __launch_bounds__(kWaves * 64) void stft2048_rgba_kernel(StftParams p
           SONO_BIN(3, z23.z, z23.w, q23.z, q23.w)
 #undef SONO_BIN
           const int kq = 128 * P + le + 64 * q;
-          if (4 * kq + 3 >= (int)p.bin_lo && 4 * kq < (int)p.bin_hi)
-            reinterpret_cast<uint2*>(slot)[rgba_flush::slot_cell<kRF>(kq, fg) * 2 + (wave & 1)] = make_uint2(shifted ? wb : wa, wb);
+          if (4 * kq + 3 >= (int)p.bin_lo && 4 * kq < (int)p.bin_hi) {
+            uint32_t* words = slot + (rgba_flush::slot_cell<kRF>(kq, fg) * 2 + (wave & 1)) * 2;
+            if constexpr (ALONE) {
+              if (mode == 2) words[1] = wa;
+              if ((mode == 1) != shifted) words[0] = wa;  // (odd end: the second frame of the pair is the one that shows)
+            } else {
+              *reinterpret_cast<uint2*>(words) = make_uint2(shifted ? wb : wa, wb);
+            }
+          }
         }
         wave_sync();  // the buffer is rewritten by the next half / the next iteration's transpose
       }
+      };  // epilogue
+      if (TABLE && mode != 0) epilogue(std::true_type{});
+      else epilogue(std::false_type{});
+    }
+    if constexpr (TABLE) {
+      if (mode == 1) {
+        // the first frame alone is done: the same pair once more for the second frame alone -- its samples (from the
+        // cache) and nothing behind them, the frame after it may lie beyond the signal
+        const uint64_t fb = f0 + 2 <= p.nframes ? f0 : p.nframes - 2;
+        const In* x1 = x + (p.frame0 + fb + 1) * p.hop + lane;
+        asm volatile("" : "+v"(x1));  // (opaque: or the samples already loaded for the pair are kept in registers instead)
+#pragma unroll
+        for (int a = 0; a < 32; ++a) raw[a] = ld<In>(x1, 64 * a);
+#pragma unroll
+        for (int a = 32; a < kRaw; ++a) raw[a] = 0.0f;
+        mode = 2;
+        continue;
+      }
+      mode = 0;
     }
     fetch(first_frame(it + 1));
     if (i == kRIters - 1) __syncthreads();  // this round's slot is complete and everyone is done reading the other one
@@ -652,6 +741,7 @@ __global__ __launch_bounds__(kWaves * 64) void stft2048_rgba_kernel(StftParams p
       for (int j = 0; j < kFPI; ++j)
         rgba_flush::flush_quarter_load<kRF>(fq[j], slots + ((nround - 1) & 1) * (kSlotBytes / 4), part_of(ni, j), unit_of(ni, j), lane);
     }
+    ++it;
   }
 }
 
@@ -728,8 +818,9 @@ int launch_stft_fast2048(const StftParams& p, void* stream_v) {
 #undef SONO_R2048_H
 #undef SONO_R2048_T
 #undef SONO_R2048
-    note_kernel(tab ? "stft2048_rgba_kernel<table>" : "stft2048_rgba_kernel<roots>");
-    note_marking(tab && p.loud_flags != nullptr);
+    // (redo: the kernel transforms its loud pairs once more, one frame at a time)
+    note_kernel(tab ? (p.loud_thr_raw > 0.0f ? "stft2048_rgba_kernel<table,redo>" : "stft2048_rgba_kernel<table>") : "stft2048_rgba_kernel<roots>");
+    note_marking(false);
     return hipGetLastError() == hipSuccess ? SONO_OK : SONO_ERR_DEVICE;
   }
 #define SONO_L2048(PL, In, FE, H)                                                                               \
@@ -752,8 +843,9 @@ int launch_stft_fast2048(const StftParams& p, void* stream_v) {
 #undef SONO_L2048_F
 #undef SONO_L2048_T
 #undef SONO_L2048
-  note_kernel(tab ? "stft2048_kernel<table>" : "stft2048_kernel<roots>");
-  note_marking(tab && p.out_kind == SONO_OUT_U8_INDEX && p.loud_flags != nullptr);
+  note_kernel(tab ? (p.out_kind == SONO_OUT_U8_INDEX && p.loud_thr_raw > 0.0f ? "stft2048_kernel<table,redo>" : "stft2048_kernel<table>")
+                  : "stft2048_kernel<roots>");
+  note_marking(false);
   return hipGetLastError() == hipSuccess ? SONO_OK : SONO_ERR_DEVICE;
 }
 

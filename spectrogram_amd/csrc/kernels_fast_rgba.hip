@@ -116,7 +116,6 @@ __global__ __launch_bounds__(kWaves * 64, 4) void stft1024_rgba_kernel(StftParam
 
   struct Unit {
     uint64_t f0;
-    uint64_t w0;  // the wavefront's first frame (wave-uniform)
     bool active, st_a, st_b, shifted;
   };
   // iteration `it` of this wavefront: four consecutive frames (two per transform).  Frames (f0, f0+1) form the complex
@@ -127,7 +126,6 @@ __global__ __launch_bounds__(kWaves * 64, 4) void stft1024_rgba_kernel(StftParam
     // of samples, so the 3/4 overlap between neighbouring groups is re-read while it is still in cache
     const uint64_t group = ((uint64_t)vb * rounds * kTileIters + it) * kWaves + wave;
     const uint64_t pair0 = group * 2;
-    u.w0 = group * 4;
     u.active = it < rounds * kTileIters && pair0 < npairs;  // wave-uniform
     if (!u.active) {            // nothing left: point at frame 0 so that the sample loads stay in bounds
       u.f0 = 0;
@@ -188,28 +186,48 @@ __global__ __launch_bounds__(kWaves * 64, 4) void stft1024_rgba_kernel(StftParam
     for (int m = 0; m < 8; ++m)
       if (64 * m + 63 >= (int)p.bin_lo && 64 * m < (int)p.bin_hi) row[m * 64 * kP] = r[m];
   };
+  auto park8_or = [&](const uint32_t (&r)[8], uint64_t k, int fg, int bin0) {  // ... OR-ed onto the dwords there
+    constexpr int kD = Ring<kRoundFrames>::kDwords, kP = Ring<kRoundFrames>::kPitch;
+    int d = (int)(((uint64_t)(kRoundFrames / 4) * k) % kD) + fg;
+    d -= d >= kD ? kD : 0;
+    uint32_t* row = slot + bin0 * kP + d;
+#pragma unroll
+    for (int m = 0; m < 8; ++m)
+      if (64 * m + 63 >= (int)p.bin_lo && 64 * m < (int)p.bin_hi) row[m * 64 * kP] |= r[m];  // (this lane's own dwords)
+  };
   bool pend_active = false;
-  for (uint64_t it = 0; it < (rounds + 2) * kTileIters; ++it) {
+  // Under the context's table a unit too loud for the pair separation (StftParams::loud_thr_raw) is transformed one frame
+  // at a time: the iteration's transform runs twice, mode 1 = frame A alone, then mode 2 = frame B alone (whose bytes are
+  // OR-ed onto frame A's).  Wave-uniform: the four frames of a wavefront go together (its halves run in lockstep anyway).
+  // A NaN sample does not compare as loud and needs no second look (it poisons every bin either way).
+  int mode = 0;
+  for (uint64_t it = 0; it < (rounds + 2) * kTileIters;) {
     const uint64_t round = it / kTileIters;
     const int sub = (int)(it % kTileIters);
     const Unit nxt = locate(it + 1);
-    // iteration 1: every wavefront has read its quarters 2, 3 of the previous round (end of its iteration 0), so the slot
-    // may be overwritten from here on
-    if (sub == 1) __syncthreads();
-    // (the empty asm is a use of the sample registers: the wait for their loads lands here, before the image stores
-    // of this iteration, and not behind them)
+    if (!(TABLE && mode == 2)) {
+      // iteration 1: every wavefront has read its quarters 2, 3 of the previous round (end of its iteration 0), so the
+      // slot may be overwritten from here on
+      if (sub == 1) __syncthreads();
+      // (the empty asm is a use of the sample registers: the wait for their loads lands here, before the image stores
+      // of this iteration, and not behind them)
 #pragma unroll
-    for (int a = 0; a < kRaw; ++a) asm volatile("" : "+v"(raw[a]));
-    if (round > 0 && rg.f_lo < rg.f_hi) {
-      const uint64_t fround = rg.f_lo + (round - 1) * kRoundFrames;
-      flush_rows(p, rg, fq[0], lut_lds, fround, 2 * sub, wave, lane);
-      flush_rows(p, rg, fq[1], lut_lds, fround, 2 * sub + 1, wave, lane);
+      for (int a = 0; a < kRaw; ++a) asm volatile("" : "+v"(raw[a]));
+      if (round > 0 && rg.f_lo < rg.f_hi) {
+        const uint64_t fround = rg.f_lo + (round - 1) * kRoundFrames;
+        flush_rows(p, rg, fq[0], lut_lds, fround, 2 * sub, wave, lane);
+        flush_rows(p, rg, fq[1], lut_lds, fround, 2 * sub + 1, wave, lane);
+      }
     }
 
     if (cur.active) {
-      if constexpr (TABLE) {  // an asymmetric table: mark the loud units for the one-frame-per-transform launch behind this one
-        if (p.loud_flags) mark_loud(p, max_abs(raw) > p.loud_thr_raw, p.frame0 + cur.w0, 4);
+      if constexpr (TABLE) {
+        if (mode == 0 && p.loud_thr_raw > 0.0f && __builtin_amdgcn_ballot_w64(max_abs(raw) > p.loud_thr_raw) != 0) mode = 1;
       }
+      const bool shifted = cur.shifted;
+      int lq = l;
+      asm volatile("" : "+v"(lq));
+      uint32_t w[16];
       float re[32], im[32];
       {
         float win[32];
@@ -222,6 +240,10 @@ __global__ __launch_bounds__(kWaves * 64, 4) void stft1024_rgba_kernel(StftParam
         for (int a = 0; a < 32; ++a) {
           re[brev5(a)] = raw[a] * win[a];
           im[brev5(a)] = raw[a + (HOP32 > 0 ? HOP32 : 32)] * win[a];
+        }
+        if (TABLE && mode != 0) {
+#pragma unroll
+          for (int a = 0; a < 32; ++a) im[a] = 0.0f;
         }
       }
       if constexpr (TABLE) {
@@ -256,14 +278,27 @@ __global__ __launch_bounds__(kWaves * 64, 4) void stft1024_rgba_kernel(StftParam
       // 24..31) through the half-wavefront's 2-KiB buffer, register r0 + j of lane l at [j][l].  Lane 0 stores one row
       // down and puts register 24 (round 0) / 0 (round 1) into row 7, so that every lane reads [j][(32 - l) mod 32].
       // Byte 0 / 1 of w[k2]: the colour indices of the transform's frames A / B at that bin.
-      const bool shifted = cur.shifted;
-      int lq = l;
-      asm volatile("" : "+v"(lq));
       const bool lane0 = lq == 0;
       unsigned char* wr = qbuf + 8 * lq - (lane0 ? 256 : 0);
       unsigned char* wr0 = lane0 ? qbuf + 7 * 256 : qbuf + 8 * lq;
       const unsigned char* rd = qbuf + 8 * ((32 - lq) & 31);
-      uint32_t w[16];
+      if (TABLE && mode != 0) {
+        // a frame alone: its spectrum is Z itself (no partner; the same factor 2 as the pair separation leaves); the
+        // other frame's byte stays 0 in this pass
+        if (mode == 1) {
+#pragma unroll
+          for (int k2 = 0; k2 < 16; ++k2) {
+            const float ar = re[k2] + re[k2], ai = im[k2] + im[k2];
+            w[k2] = put_index<PLUGIN, 0>(__builtin_fmaf(ar, ar, ai * ai), fs, 0u);
+          }
+        } else {
+#pragma unroll
+          for (int k2 = 0; k2 < 16; ++k2) {
+            const float ar = re[k2] + re[k2], ai = im[k2] + im[k2];
+            w[k2] = put_index<PLUGIN, 1>(__builtin_fmaf(ar, ar, ai * ai), fs, 0u);
+          }
+        }
+      } else {
 #pragma unroll
       for (int R = 0; R < 2; ++R) {
         const int r0 = 16 + 8 * R, rx = (24 + 8 * R) & 31;
@@ -283,6 +318,7 @@ __global__ __launch_bounds__(kWaves * 64, 4) void stft1024_rgba_kernel(StftParam
         }
         wave_sync();  // the buffer is rewritten by the next round / the next iteration's transpose
       }
+      }
       // an odd last frame was computed as B: it belongs in the A byte (one half-wavefront per launch)
       if (__builtin_amdgcn_ballot_w64(shifted) != 0) {
 #pragma unroll
@@ -298,10 +334,27 @@ __global__ __launch_bounds__(kWaves * 64, 4) void stft1024_rgba_kernel(StftParam
       }
       if (sub == 0) {
 #pragma unroll
-        for (int m = 0; m < 8; ++m) pend[m] = r8[m];
+        for (int m = 0; m < 8; ++m) pend[m] = (TABLE && mode == 2) ? pend[m] | r8[m] : r8[m];
+      } else if (TABLE && mode == 2) {
+        park8_or(r8, round, kWaves + wave, lq + 32 * h);  // (onto what the pass for frame A left there)
       } else {
         park8(r8, round, kWaves + wave, lq + 32 * h);
       }
+    }
+    if constexpr (TABLE) {
+      if (mode == 1) {
+        // frame A alone is done: the same unit once more for frame B alone -- its samples (from the cache) and nothing
+        // behind them, the frame after it may lie beyond the signal
+        const In* xb1 = x + (p.frame0 + cur.f0 + 1) * p.hop + l;
+        asm volatile("" : "+v"(xb1));  // (opaque: or the samples already loaded for the pair are kept in registers instead)
+#pragma unroll
+        for (int a = 0; a < 32; ++a) raw[a] = ld<In>(xb1, 32 * a);
+#pragma unroll
+        for (int a = 32; a < kRaw; ++a) raw[a] = 0.0f;
+        mode = 2;
+        continue;
+      }
+      mode = 0;
     }
     if (sub == 0) {
       pend_active = cur.active;
@@ -320,6 +373,7 @@ __global__ __launch_bounds__(kWaves * 64, 4) void stft1024_rgba_kernel(StftParam
       __syncthreads();
       if (round <= rounds) read_rows(fq, 0, round);
     }
+    ++it;
   }
 }
 
@@ -364,8 +418,8 @@ int launch_stft_fast_rgba(const StftParams& p, void* stream_v) {
 #undef SONO_LAUNCH
 #undef SONO_LAUNCH_HOP
 #undef SONO_LAUNCH_T
-  note_kernel(tab ? "stft1024_rgba_kernel<table>" : "stft1024_rgba_kernel<roots>");
-  note_marking(tab && p.loud_flags != nullptr);
+  note_kernel(tab ? (p.loud_thr_raw > 0.0f ? "stft1024_rgba_kernel<table,redo>" : "stft1024_rgba_kernel<table>") : "stft1024_rgba_kernel<roots>");
+  note_marking(false);  // (under a table the kernel redoes its loud units itself)
   return hipGetLastError() == hipSuccess ? SONO_OK : SONO_ERR_DEVICE;
 }
 

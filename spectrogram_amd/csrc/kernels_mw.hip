@@ -439,7 +439,7 @@ int launch_stft_mw(const StftParams& p, void* stream_v) {
   // one frame per transform where two would not do: float32 outputs under an asymmetric table (StftParams::pair_exact),
   // colour indices under a table whose cross-talk could show (StftParams::pair_idx_ok)
   // (this kernel's pairing flavour marks nothing: where the caller relies on marks it transforms one frame at a time)
-  const bool single = (flt && !p.pair_exact) || (u8 && (!p.pair_idx_ok || p.loud_flags)) || marked;
+  const bool single = (flt && !p.pair_exact) || (u8 && (!p.pair_idx_ok || p.loud_flags || p.loud_thr_raw > 0.0f)) || marked;
   // a non-linear frequency scale: colour indices only, plugin quantiser
   const bool bank = p.fb_packed != nullptr;
   if (bank && (!u8 || p.scale_mode != SONO_SCALE_PLUGIN_DB)) return 1;

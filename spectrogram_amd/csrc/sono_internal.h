@@ -87,8 +87,6 @@ void note_marking(bool marks);
 int launch_stft_general(const StftParams& p, bool exact_f64, void* hip_stream);
 // kernels_fast.hip: float32 kernels with accurate twiddles (returns 1 if this size/mode has no fast kernel).
 int launch_stft_fast(const StftParams& p, void* hip_stream);
-// ... and the launch behind it that recomputes the units it marked, one frame per transform (StftParams::loud_flags).
-int launch_stft_fast_loud(const StftParams& p, void* hip_stream);
 void build_fast_table_1024(std::vector<float>& t);
 // kernels_fast_rgba.hip: the 1024-point kernel that writes the RGBA image itself, colour-index exchange in LDS.
 int launch_stft_fast_rgba(const StftParams& p, void* hip_stream);

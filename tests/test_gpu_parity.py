@@ -272,8 +272,8 @@ def test_colour_indices_within_one_lsb_under_near_full_scale_tones(n):
             assert d.max() <= 1 and (d != 0).mean() < 0.02, (n, trial, f, amp, noise, int((d > 1).sum()))
         route = eng.kernel_route()
     assert route == {512: "stft512_kernel<table> + stft_mw_kernel<512,single,marked>",
-                     1024: "stft1024_u8_kernel<table> + stft1024_u8_kernel<table,single,marked>",
-                     2048: "stft2048_kernel<table> + stft_mw_kernel<2048,single,marked>",
+                     1024: "stft1024_u8_kernel<table,redo>",
+                     2048: "stft2048_kernel<table,redo>",
                      4096: "stft4096_kernel + stft_mw_kernel<4096,single,marked>"}[n], route
 
 
@@ -453,9 +453,8 @@ def test_kernel_route_is_visible_and_default_view_is_fast():
         assert eng.kernel_route() == ""
         eng.set_colormap(lut)
         img = eng.stft(x)
-        # (+ the launches that recompute, one frame per transform, the units the image writer marked as loud and write
-        # their columns)
-        assert eng.kernel_route() == "stft1024_rgba_kernel<table>:rgba + stft1024_u8_kernel<table,single,marked> + colorize_marked_kernel"
+        # (redo: the image writer transforms its loud units one frame at a time)
+        assert eng.kernel_route() == "stft1024_rgba_kernel<table,redo>:rgba"
     want = ref[:, lo:hi].T[::-1].astype(np.int16)
     l4 = lut.reshape(256, 4)
     ok = np.zeros(want.shape, bool)
@@ -484,14 +483,14 @@ def test_one_frame_per_transform_where_pairing_would_leak():
     Hermitian, so two frames that share a complex transform do not separate exactly: a bin is off by at most g x the
     pair's largest sample (g: the defect's operator norm for this table and window, computed when the context is made).
     At the default gain / range that could move a colour index near the -100 dB floor by more than a step once samples
-    exceed a few hundredths of full scale, so the 1024-point kernel marks the loud units and a second launch recomputes
-    them with one real frame per transform, whose spectrum is the reference's own transform of that frame; a display
+    exceed a few hundredths of full scale, so the 1024-point kernel transforms its loud units once more, one real
+    frame per transform, whose spectrum is the reference's own transform of that frame (<table,redo>); a display
     floor the defect cannot reach keeps the pairs alone; float32 dB output has no floor at all and never pairs."""
     rng = np.random.default_rng(1024)
     L = 1024 + 256 * 700 + 3
     x = (rng.standard_normal(L) * 1e-4).astype(np.float32)
     x[256 * 200:256 * 200 + 1024] += 0.9 * np.sin(np.arange(1024) * 0.61).astype(np.float32)   # one loud frame span
-    both = "stft1024_u8_kernel<table> + stft1024_u8_kernel<table,single,marked>"
+    both = "stft1024_u8_kernel<table,redo>"
     for window in ("rectangular", "hann"):
         ref = oracle.plugin_get_frequencies(x, 1024, 768, window=window)
         with plugin_engine(1024, 256, F.ARITH_FAST_F32, window=window) as eng:
@@ -517,7 +516,7 @@ def test_one_frame_per_transform_where_pairing_would_leak():
     ref = oracle.plugin_get_frequencies(y, 2048, 1536, window="rectangular")
     with plugin_engine(2048, 512, F.ARITH_FAST_F32, window="rectangular") as eng:
         got = eng.stft(y)
-        assert eng.kernel_route() == "stft2048_kernel<table> + stft_mw_kernel<2048,single,marked>"
+        assert eng.kernel_route() == "stft2048_kernel<table,redo>"
     assert got.shape == ref.shape and cyc_diff(got, ref).max() <= 1 and (got == ref).mean() > 0.98
     _, mags, _, _ = oracle.plugin_get_frequencies(y, 512, 384, want_mags=True)
     with plugin_engine(512, 128, F.ARITH_FAST_F32, out_kind=F.OUT_F32_DB) as eng:
@@ -551,13 +550,13 @@ def test_one_frame_and_filter_bank_flavours_over_hops_inputs_and_lengths(flavour
     kw = dict(in_kind=F.IN_I16 if i16 else F.IN_F32, bin_lo=lo, bin_hi=hi)
     if flavour == "single":
         ref = oracle.plugin_get_frequencies(x, n, n - hop, window="rectangular")
-        route = "stft1024_u8_kernel<table> + stft1024_u8_kernel<table,single,marked>"
+        route = "stft1024_u8_kernel<table,redo>"
         with plugin_engine(n, hop, F.ARITH_FAST_F32, window="rectangular", **kw) as eng:
             got = eng.stft(x_in)
             assert eng.kernel_route() == route
     else:
         ref = oracle.plugin_get_frequencies_scaled(x, n, n - hop, "mel", sr)
-        route = "stft1024_u8_kernel<table,single,bank>"
+        route = "stft1024_u8_kernel<table,bank,redo>"
         with plugin_engine(n, hop, F.ARITH_FAST_F32, **kw) as eng:
             eng.set_filterbank(*E.filterbank_table("mel", n, sr))
             got = eng.stft(x_in)
@@ -828,7 +827,7 @@ def test_scaled_frequencies_stay_on_the_float32_kernels(n, hop, scale):
         eng.set_filterbank(*fb)
         got = eng.stft(x)
         route = eng.kernel_route()
-    fused = {1024: "stft1024_u8_kernel<table,single,bank>", 512: "stft_mw_kernel<512,single,bank>",
+    fused = {1024: "stft1024_u8_kernel<table,bank,redo>", 512: "stft_mw_kernel<512,single,bank>",
              2048: "stft_mw_kernel<2048,single,bank>", 4096: "stft_mw_kernel<4096,single,bank>"}[n]
     assert route == fused, route
     d = cyc_diff(got, ref)

@@ -22,12 +22,13 @@ int main(int argc, char** argv) {
   const uint32_t hop = argc > 5 ? (uint32_t)atoi(argv[5]) : 256;
   const uint64_t L = (uint64_t)seconds * 384000ull;
   std::vector<float> x(L);
+  const float pulse_amp = getenv("SONO_BENCH_PULSE") ? (float)atof(getenv("SONO_BENCH_PULSE")) : 0.3f;  // peak of the calls
   uint32_t s = 12345;
   for (uint64_t i = 0; i < L; i++) {
     s = (1103515245u * s + 12345u) & 0x7fffffffu;
     float v = 0.01f * (2.0f * (float)s / 2147483648.0f - 1.0f);
     const uint64_t p = i % 30720;  // 80 ms
-    if (p < 1920) v += 0.3f * 0.5f * (1.0f - cosf(6.2831853f * (float)p / 1920.0f)) * sinf(1.2f * (float)p - 1.6e-4f * (float)p * (float)p);
+    if (p < 1920) v += pulse_amp * 0.5f * (1.0f - cosf(6.2831853f * (float)p / 1920.0f)) * sinf(1.2f * (float)p - 1.6e-4f * (float)p * (float)p);
     x[i] = v;
   }
   sono_config cfg;
