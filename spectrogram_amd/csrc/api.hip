@@ -61,7 +61,8 @@ struct sono_ctx {
   bool loud_marks = false;
   bool split_ok = true;     // StftParams::split_ok
   float loud_thr_raw = 0.0f, loud_thr_win = 0.0f;
-  uint8_t* d_loud = nullptr;   // kLoudFlagBytes of marks
+  uint8_t* d_loud = nullptr;   // kLoudFlagBytes of marks (512 points)
+  void* d_redo = nullptr;      // StftParams::redo_scratch (4096 points)
   std::string route;        // kernels of the most recent transform call (sono_kernel_route)
   std::string err;
 };
@@ -334,7 +335,7 @@ void sono_destroy(sono_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
-  void* bufs[] = {c->d_window, c->d_tw, c->d_tw_exact, c->d_claim, c->d_lut, c->d_fast, c->d_in, c->d_out, c->d_aux, c->d_fb_bin, c->d_fb_w, c->d_fb_packed, c->d_loud};
+  void* bufs[] = {c->d_window, c->d_tw, c->d_tw_exact, c->d_claim, c->d_lut, c->d_fast, c->d_in, c->d_out, c->d_aux, c->d_fb_bin, c->d_fb_w, c->d_fb_packed, c->d_loud, c->d_redo};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
   if (c->ev_start) (void)hipEventDestroy(c->ev_start);
@@ -561,7 +562,8 @@ static int refresh_routes(sono_ctx* c) {
       c->loud_marks = true;
       c->loud_thr_raw = (float)thr_raw;
       c->loud_thr_win = (float)thr_win;
-      if (n != 1024 && n != 2048 && !c->d_loud) HIP_TRY(c, hipMalloc((void**)&c->d_loud, kLoudFlagBytes));
+      if (n == 512 && !c->d_loud) HIP_TRY(c, hipMalloc((void**)&c->d_loud, kLoudFlagBytes));
+      if (n == 4096 && !c->d_redo) HIP_TRY(c, hipMalloc(&c->d_redo, redo_scratch_bytes()));
     }
     // (the 4096-point kernel without marks would be unsafe: see launch_range)
   }
@@ -614,14 +616,16 @@ static int launch_range(sono_ctx* c, const StftParams& q_in, const IndexScratch&
   StftParams q = q_in;
   // An asymmetric table whose pairs (1024 points) or split frames (4096 points) are safe only below a sample level: the
   // kernels mark the loud units and a one-frame-per-transform launch recomputes them (refresh_routes).
-  const bool loud = c->loud_marks && (c->d_loud || q_in.n == 1024 || q_in.n == 2048) && !exact && q_in.nframes >= 16 &&
+  const bool loud = c->loud_marks && (q_in.n == 512 ? c->d_loud != nullptr : q_in.n == 4096 ? c->d_redo != nullptr : true) && !exact && q_in.nframes >= 16 &&
                     (q_in.out_kind == SONO_OUT_U8_INDEX || rgba) &&
                     (!q_in.fb_bin || (q_in.n == 1024 && fb_fused && fb_1024));  // (a filter bank: the 1024-point kernel alone)
   if (loud) {
-    if (q.n != 1024 && q.n != 2048) {  // (the 1024- and 2048-point kernels transform their loud units once more themselves)
+    // (the 1024-, 2048- and 4096-point kernels transform their loud units once more themselves)
+    if (q.n == 512) {
       q.loud_flags = c->d_loud;
       q.loud_mask = (uint32_t)(kLoudFlagBytes - 1);
     }
+    if (q.n == 4096) q.redo_scratch = c->d_redo;
     q.loud_thr_raw = c->loud_thr_raw;
     q.loud_thr_win = c->loud_thr_win;
     if (q.n != 4096) q.pair_idx_ok = 1;  // (4096 points: the pairing three-pass kernel stays off, the splitting kernel marks)

@@ -326,9 +326,6 @@ __global__ __launch_bounds__(Geo<N>::kWaves * 64) void stft_exact_kernel(StftPar
 }  // namespace exactreg
 
 bool exact_available(const StftParams& p) {
-#ifdef SONO_EXP_EXACT1024ONLY
-  if (p.n != 1024) return false;
-#endif
   return (p.n == 512 || p.n == 1024 || p.n == 2048 || p.n == 4096) && p.twiddles && !p.fb_bin && p.nframes >= 16 &&
          (p.out_kind == SONO_OUT_U8_INDEX || p.out_kind == SONO_OUT_F32_DB || p.out_kind == SONO_OUT_F32_MAG ||
           p.out_kind == SONO_OUT_FEATURES);

@@ -66,6 +66,10 @@ constexpr int lds_bytes(int waves) { return kTwBytes + kWinBytes + waves * 2 * k
 // kOutU8Bank: colour indices on a non-linear frequency scale: out[y] = m[tap[y]] * w0[y] + m[tap[y] + 1] * w1[y] over the
 // frame's magnitudes (spectrogram.esm.js:479-488 with the two non-zero weights of a row), then the quantiser.
 constexpr int kOutU8 = 0, kOutFeatures = 2, kOutDb = 3, kOutMag = 4, kOutU8Bank = 5;
+#ifndef SONO_SYNC_ITERS
+#define SONO_SYNC_ITERS 4
+#endif
+constexpr int kSyncIters = SONO_SYNC_ITERS;  // iterations between two barriers of the index kernel's wavefronts
 template <bool PLUGIN, typename In, int HOP32, int OUT, bool TABLE>
 __global__ __launch_bounds__(kMaxWaves * 64, 4) void stft1024_u8_kernel(StftParams p, FastScale fs,
                                                                         const float2* __restrict__ tw_table) {
@@ -179,7 +183,16 @@ __global__ __launch_bounds__(kMaxWaves * 64, 4) void stft1024_u8_kernel(StftPara
   Unit cur = locate(it);
   fetch(cur, false);
   int mode = 0;  // REDO: 0 = the pair (A, B) in one transform; 1 / 2 = frame A / frame B alone.  Wave-uniform.
-  while (cur.active) {
+  // Every wavefront of the workgroup goes through all `iters` iterations, with or without frames of its own, and they
+  // meet at a barrier every kSyncIters of them: left alone they drift apart by more than an iteration, and the samples
+  // that neighbouring wavefronts share (3/4 of a frame group at hop = N/4) are then fetched from memory again --
+  // the L2 of an XCD turns over once per iteration (measured: 1.32 x the input bytes without the barrier).
+  while (it < iters) {
+    if (mode == 0 && it != 0 && it % kSyncIters == 0) __syncthreads();
+    if (!cur.active) {  // (nothing left for this wavefront: every later unit of it is inactive as well)
+      ++it;
+      continue;
+    }
     const uint64_t f0 = cur.f0;  // the frame whose row the first result goes to
     const bool st_a = cur.st_a;
     bool st_b = SINGLE ? false : cur.st_b;

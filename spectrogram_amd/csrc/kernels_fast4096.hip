@@ -187,7 +187,13 @@ __global__ __launch_bounds__(kWaves * 64) void stft4096_kernel(StftParams p, Fas
   // this lane's cells of iteration `i`: bin quad qlo + tq, frame group lane & (kGroups - 1)
   auto flush_quad = [&](int i, int s) { return ((i * kFlushPasses + s) * kWaves + wave) * (64 / kGroups) + lane / kGroups; };
   uint4 fq[kFlushPasses] = {};
-  for (uint64_t it = 0; it < (rounds + (RGBA ? 1 : 0)) * kRoundIters; ++it) {
+  // A frame's even and odd samples are transformed as one complex frame; under the context's table that split carries
+  // the same kind of trace as a pair of frames does (StftParams::loud_thr_raw).  A frame too loud for it is transformed
+  // twice more: mode 1 = its even samples alone, whose transform E is parked in this wavefront's 16 KiB of p.redo_scratch,
+  // mode 2 = its odd samples alone, whose transform O meets E again in the epilogue.  Wave-uniform.
+  float2* park = reinterpret_cast<float2*>(p.redo_scratch) + ((size_t)blockIdx.x * kWaves + wave) * 2048;
+  int mode = 0;
+  for (uint64_t it = 0; it < (rounds + (RGBA ? 1 : 0)) * kRoundIters;) {
     const uint64_t round = it / kRoundIters;
     const int i = (int)(it % kRoundIters);
     const uint64_t f = round < rounds ? (round * gridDim.x + vb) * kRoundFrames + kWaves * i + wave : p.nframes;
@@ -197,10 +203,10 @@ __global__ __launch_bounds__(kWaves * 64) void stft4096_kernel(StftParams p, Fas
       const int v = lane & 31, u = lane >> 5;
       const In* x0 = x + (p.frame0 + (active ? f : 0)) * p.hop + 128 * 16 * u + 4 * v;
 #pragma unroll
-      for (int a = 0; a < 16; ++a) raw[a] = ld4<In>(x0 + 128 * a);
+      for (int a = 0; a < 16; ++a) raw[a] = ld4<In>(x0 + 128 * a);  // (mode 2: the same samples again, from the cache)
     }
     if constexpr (RGBA) {
-      if (round > 0) {  // write out this lane's share of the round before, parked in fq at the end of the last iteration
+      if (round > 0 && mode != 2) {  // write out this lane's share of the round before, parked in fq at the end of the last iteration
         const uint64_t frame0 = ((round - 1) * gridDim.x + vb) * kRoundFrames;
         if (frame0 < p.nframes) {
           int w = wave, j = lane;
@@ -243,15 +249,14 @@ __global__ __launch_bounds__(kWaves * 64) void stft4096_kernel(StftParams p, Fas
     }
 
     if (active) {
-      // (the frame's even and odd samples are transformed as one complex frame: under the asymmetric table the split
-      // carries the same kind of trace as a pair of frames does, so loud frames are marked for the launch behind this one)
-      if (p.loud_flags) {
+      if (mode == 0 && p.loud_thr_raw > 0.0f && p.redo_scratch) {
+        // (a NaN sample does not compare as loud and needs no second look: it poisons every bin either way)
         float m = 0.0f;
 #pragma unroll
         for (int a = 0; a < 16; ++a)
           m = __builtin_fmaxf(m, __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(raw[a].x), __builtin_fabsf(raw[a].y)),
                                                  __builtin_fmaxf(__builtin_fabsf(raw[a].z), __builtin_fabsf(raw[a].w))));
-        mark_loud(p, m > p.loud_thr_raw, p.frame0 + f, 1);
+        if (__builtin_amdgcn_ballot_w64(m > p.loud_thr_raw) != 0) mode = 1;
       }
       float re[32], im[32];
       {
@@ -268,32 +273,71 @@ __global__ __launch_bounds__(kWaves * 64) void stft4096_kernel(StftParams p, Fas
           re[brev5(16 + a)] = s2; im[brev5(16 + a)] = s3;
         }
       }
+      if (mode == 1) {  // the even samples alone
+#pragma unroll
+        for (int a = 0; a < 32; ++a) im[a] = 0.0f;
+      } else if (mode == 2) {  // the odd samples alone
+#pragma unroll
+        for (int a = 0; a < 32; ++a) {
+          re[a] = im[a];
+          im[a] = 0.0f;
+        }
+      }
       int lt = lane;
       asm volatile("" : "+v"(lt));  // (keeps the transform's loop-invariant LDS addresses out of registers it needs itself)
       transform2048(re, im, tw_lds, tw_flat, blk, lt);
+      if (mode == 1) {
+        // E[k1 + 32m + 1024hb] is register m of lane k1 + 32hb: parked for the epilogue of the next pass of this loop.
+        // (The lanes that read a value back are not the ones that wrote it, but they are lanes of this wavefront: the
+        // stores have left the compute unit's write-through vector cache once the fence of workgroup scope has passed,
+        // and no other compute unit ever touches this wavefront's 16 KiB.)
+        float2* e0 = park + (lt & 31) + 1024 * (lt >> 5);
+#pragma unroll
+        for (int m = 0; m < 32; ++m) e0[32 * m] = make_float2(re[m], im[m]);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        mode = 2;
+        continue;
+      }
 
       int le = lane;
       asm volatile("" : "+v"(le));
       const uint64_t row = (p.col0 + f) * p.out_bins;
       uint32_t* slot = RGBA ? slots + (round & 1) * kSlotWords + ((kWaves * i + wave) >> 2) * (512 * 4) + (wave & 3) : nullptr;
-      auto pass = [&](auto P8c) {
+      // ALONE (mode 2): the registers hold O, the transform of the odd samples alone; E comes back from where mode 1
+      // parked it, and the last stage runs on 2 E and 2 O -- the same factor 2 as the split's separation leaves.
+      auto pass = [&](auto P8c, auto alone_c) __attribute__((always_inline)) {
         constexpr int P8 = decltype(P8c)::value;
+        constexpr bool ALONE = decltype(alone_c)::value;
         if (kPassBins * (P8 + 1) <= (int)p.bin_lo || kPassBins * P8 >= (int)p.bin_hi) return;  // wave-uniform
+        const int k = kPassBins * P8 + 4 * le;
+        float4 e01 = make_float4(0, 0, 0, 0), e23 = e01;
+        if constexpr (ALONE) {  // (requested before the exchange through LDS, used after it)
+          const float4* ep = reinterpret_cast<const float4*>(park + k);
+          e01 = ep[0];
+          e23 = ep[1];
+        }
         epilogue_cells<P8>(re, im, wbuf, le);
         wave_sync();
-        const int k = kPassBins * P8 + 4 * le;
         const unsigned char* zr = wbuf + 16 * le;
-        const float4 z01 = *reinterpret_cast<const float4*>(zr);
-        const float4 z23 = *reinterpret_cast<const float4*>(zr + kPlane1);
-        const float4 q01 = *reinterpret_cast<const float4*>(zr + kRegion);
-        const float4 q23 = *reinterpret_cast<const float4*>(zr + kRegion + kPlane1);
+        float4 z01 = *reinterpret_cast<const float4*>(zr);
+        float4 z23 = *reinterpret_cast<const float4*>(zr + kPlane1);
+        float4 q01 = *reinterpret_cast<const float4*>(zr + kRegion);
+        float4 q23 = *reinterpret_cast<const float4*>(zr + kRegion + kPlane1);
+        if constexpr (ALONE) {
+          // the values read back are O[k .. k+3]; E takes the place of Z and O the place of the partner below
+          q01 = z01;
+          q23 = z23;
+          z01 = e01;
+          z23 = e23;
+        }
         const float4 w01 = reinterpret_cast<const float4*>(last_lds)[64 * P8 + le];
         const float4 w23 = reinterpret_cast<const float4*>(last_lds)[512 + 64 * P8 + le];
         uint32_t word = 0;
 #define SONO_BIN(B, ZR, ZI, PR, PI, WR, WI)                                  \
   {                                                                          \
-    const float ar = (ZR) + (PR), ai = (ZI) - (PI); /* 2 E[k] */             \
-    const float br = (ZI) + (PI), bi = (PR) - (ZR); /* 2 O[k] */             \
+    /* ALONE: (ZR, ZI) is E[k] and (PR, PI) is O[k] themselves */            \
+    const float ar = ALONE ? (ZR) + (ZR) : (ZR) + (PR), ai = ALONE ? (ZI) + (ZI) : (ZI) - (PI); /* 2 E[k] */ \
+    const float br = ALONE ? (PR) + (PR) : (ZI) + (PI), bi = ALONE ? (PI) + (PI) : (PR) - (ZR); /* 2 O[k] */ \
     const float xr = __builtin_fmaf(-(WI), bi, __builtin_fmaf((WR), br, ar)); \
     const float xi = __builtin_fmaf((WI), br, __builtin_fmaf((WR), bi, ai)); \
     word = put_index<PLUGIN, B>(__builtin_fmaf(xr, xr, xi * xi), fs, word);  \
@@ -310,14 +354,19 @@ __global__ __launch_bounds__(kWaves * 64) void stft4096_kernel(StftParams p, Fas
         }
         wave_sync();  // the buffer is rewritten by the next pass / the next iteration's transpose
       };
-      pass(std::integral_constant<int, 0>{});
-      pass(std::integral_constant<int, 1>{});
-      pass(std::integral_constant<int, 2>{});
-      pass(std::integral_constant<int, 3>{});
-      pass(std::integral_constant<int, 4>{});
-      pass(std::integral_constant<int, 5>{});
-      pass(std::integral_constant<int, 6>{});
-      pass(std::integral_constant<int, 7>{});
+      auto passes = [&](auto alone_c) __attribute__((always_inline)) {
+        pass(std::integral_constant<int, 0>{}, alone_c);
+        pass(std::integral_constant<int, 1>{}, alone_c);
+        pass(std::integral_constant<int, 2>{}, alone_c);
+        pass(std::integral_constant<int, 3>{}, alone_c);
+        pass(std::integral_constant<int, 4>{}, alone_c);
+        pass(std::integral_constant<int, 5>{}, alone_c);
+        pass(std::integral_constant<int, 6>{}, alone_c);
+        pass(std::integral_constant<int, 7>{}, alone_c);
+      };
+      if (mode == 2) passes(std::true_type{});
+      else passes(std::false_type{});
+      mode = 0;
     }
 
     if constexpr (RGBA) {
@@ -333,6 +382,7 @@ __global__ __launch_bounds__(kWaves * 64) void stft4096_kernel(StftParams p, Fas
         }
       }
     }
+    ++it;
   }
 }
 
@@ -340,13 +390,15 @@ __global__ __launch_bounds__(kWaves * 64) void stft4096_kernel(StftParams p, Fas
 
 static bool fast4096_common(const StftParams& p) {
   if (p.n != 4096 || p.nframes < 1 || p.fast_mode != 2 || !p.twiddles) return false;
-  if (!p.split_ok && !p.loud_flags) return false;  // the split's trace could show and nobody recomputes the loud frames
-  if (p.loud_only) return false;                  // (the launch that recomputes them is a one-frame-per-transform kernel)
+  // the split's trace could show: the kernel transforms the loud frames' even and odd samples apart, given the scratch
+  if (!p.split_ok && !(p.loud_thr_raw > 0.0f && p.redo_scratch)) return false;
   if (p.hop & 3) return false;  // frames start on 16-byte (float) / 8-byte (int16) boundaries
   const uintptr_t align = p.in_kind == SONO_IN_I16 ? 7 : 15;
   if (reinterpret_cast<uintptr_t>(p.pcm) & align) return false;
   return p.bin_lo < p.bin_hi && p.bin_hi <= 2048;
 }
+
+uint64_t redo_scratch_bytes() { return (uint64_t)device_cu_count() * fast4096::kWaves * 2048 * 8; }
 
 // Colour indices [frame][bin]: whole groups of four bins.
 bool fast4096_available(const StftParams& p) {
@@ -374,8 +426,7 @@ int launch_stft_fast4096(const StftParams& p, void* stream_v) {
   const int cus = device_cu_count();
   if (rgba && (uint64_t)cus * 2 * kSlotWords * 4 > fast_rgba_scratch_bytes()) return 1;
   // rounds of 32 frames when a workgroup would get fewer than 16 rounds of 64
-  int rf = rgba && (p.nframes + 63) / 64 < (uint64_t)16 * cus ? 32 : 64;
-  if (const char* e = getenv("SONO_4096_ROUND")) rf = atoi(e) == 32 ? 32 : atoi(e) == 64 ? 64 : rf;  // (A/B runs and tests)
+  const int rf = rgba && (p.nframes + 63) / 64 < (uint64_t)16 * cus ? 32 : 64;
   const uint64_t need = (p.nframes + rf - 1) / rf;
   const uint32_t grid = (uint32_t)(need < (uint64_t)cus ? need : (uint64_t)cus);  // persistent: one workgroup per CU
   uint8_t* tiles = reinterpret_cast<uint8_t*>(p.tile_scratch);
@@ -395,8 +446,10 @@ int launch_stft_fast4096(const StftParams& p, void* stream_v) {
   else { if (plugin) SONO_L4096_I(true, 0); else SONO_L4096_I(false, 0); }
 #undef SONO_L4096_I
 #undef SONO_L4096
-  note_kernel(rgba ? "stft4096_kernel<image>" : "stft4096_kernel");
-  note_marking(p.loud_flags != nullptr);
+  // (redo: the kernel transforms the even and the odd samples of a loud frame apart)
+  const bool redo = !p.split_ok;
+  note_kernel(rgba ? (redo ? "stft4096_kernel<image,redo>" : "stft4096_kernel<image>") : redo ? "stft4096_kernel<redo>" : "stft4096_kernel");
+  note_marking(false);
   return hipGetLastError() == hipSuccess ? SONO_OK : SONO_ERR_DEVICE;
 }
 

@@ -71,9 +71,6 @@ __host__ __device__ inline ExactPred make_exact_pred(uint32_t mode, uint32_t n, 
   return q;
 }
 __device__ __forceinline__ uint32_t worker_index_exact_p(float re, float im, const ExactPred& q) {
-#ifdef SONO_EXP_NOPRED
-  return worker_index_exact(re, im);
-#endif
   const float t = __log2f(__builtin_fmaf(re, re, im * im)) * q.a;
   const float fr = __builtin_amdgcn_fractf(t);
   if (t > q.tol && t < 255.0f - q.tol && fr > q.tol && fr < 1.0f - q.tol) return (uint32_t)t;
@@ -83,9 +80,6 @@ __device__ __forceinline__ uint32_t worker_index_exact_p(float re, float im, con
 }
 __device__ __forceinline__ uint32_t plugin_index_exact_p(float re, float im, double two_over_n, double gain, double range,
                                                          const ExactPred& q) {
-#ifdef SONO_EXP_NOPRED
-  return plugin_index_exact(plugin_mag_exact(re, im, two_over_n), gain, range);
-#endif
   if (q.on) {
     const float t = __builtin_fmaf(__log2f(__builtin_fmaf(re, re, im * im)), q.a, q.b);
     const float fr = __builtin_amdgcn_fractf(t);

@@ -75,7 +75,10 @@ struct StftParams {
   float loud_thr_win;     // ... or its largest |sample * window| above this (kernels that keep no raw samples)
   uint32_t loud_only;     // the second launch: units without a mark are skipped
   uint32_t split_ok;      // 4096 points: a frame may be transformed as its even and odd samples in one complex frame
-                          // without marks (symmetric table, or a display floor its defect cannot reach)
+                          // whatever its level (symmetric table, or a display floor its defect cannot reach)
+  void* redo_scratch;     // device, 4096 points under a table whose split is not safe at every level: 16 KiB per wavefront of
+                          // the launch (redo_scratch_bytes()), where the kernel parks the even samples' transform of a loud
+                          // frame while it transforms the odd samples alone
 };
 
 // Every launch_* function reports the kernel it enqueued (a static string), for sono_kernel_route.
@@ -102,6 +105,7 @@ int launch_stft_fast2048(const StftParams& p, void* hip_stream);
 // RGBA image itself (given tile_scratch).  Returns 1 if it does not serve this launch.
 int launch_stft_fast4096(const StftParams& p, void* hip_stream);
 bool fast4096_available(const StftParams& p);
+uint64_t redo_scratch_bytes();
 bool fast4096_rgba_available(const StftParams& p);
 void build_fast_table_2048(std::vector<float>& t);
 // kernels_mw.hip: float32 kernel for 2048- and 4096-point frames with the context's twiddle table

@@ -67,11 +67,11 @@ def test_fft4096_band_crop_rgba_fast_against_checker():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("hop,in_kind,round_frames", [(256, "f32", 32), (256, "f32", 64), (1024, "i16", 64), (204, "f32", 32),
-                                                      (1022, "f32", 0)])
-def test_fft4096_kernel_indices_and_image(hop, in_kind, round_frames, monkeypatch):
+@pytest.mark.parametrize("hop,in_kind", [(256, "f32"), (1024, "i16"), (204, "f32"), (1022, "f32")])
+def test_fft4096_kernel_indices_and_image(hop, in_kind):
     """The 4096-point kernel (one wavefront per frame: complex 2048-point transform of even/odd samples + the reference's
-    last stage): [frame][bin] indices within 1 LSB of the checker; the image it writes itself, at both round sizes, with
+    last stage): [frame][bin] indices within 1 LSB of the checker; the image it writes itself (rounds of 32 frames at
+    this length; test_fft4096_image_rounds_of_64_frames covers the long-recording flavour), with
     a band that starts and ends inside a group of four bins, equals the colour map applied to those indices.  A hop that
     is not a multiple of four samples cannot take that kernel's 16-byte sample loads; the three-pass kernel would serve
     it, but with two frames per transform the recurrence factors at 4096 points let a full-scale frame leave a trace
@@ -88,15 +88,13 @@ def test_fft4096_kernel_indices_and_image(hop, in_kind, round_frames, monkeypatc
         src = np.round(np.clip(x, -1, 1) * 32767).astype(np.int16)
         x = (src.astype(np.float32) / 32768.0).astype(np.float32)
         kw["in_kind"] = F.IN_I16
-    if round_frames:
-        monkeypatch.setenv("SONO_4096_ROUND", str(round_frames))
     ref = oracle.plugin_get_frequencies(x, n, n - hop)
     with plugin_engine(n, hop, **kw) as eng:
         got = eng.stft(src)
         route = eng.kernel_route()
     # (the kernel splits a frame into its even and odd samples; under the recurrence table that split is safe only below a
-    # sample level, so it marks the loud frames -- this signal is loud -- and a one-frame-per-transform launch redoes them)
-    assert route == ("stft4096_kernel + stft_mw_kernel<4096,single,marked>" if hop % 4 == 0 else "stft_mw_kernel<4096,single>"), route
+    # sample level, so it transforms the even and the odd samples of a loud frame apart -- this signal is loud)
+    assert route == ("stft4096_kernel<redo>" if hop % 4 == 0 else "stft_mw_kernel<4096,single>"), route
     d = np.abs(got.astype(np.int16) - ref.astype(np.int16))
     d = np.minimum(d, 256 - d)
     assert got.shape == ref.shape and d.max() <= 1 and (d != 0).mean() < 0.02
@@ -108,11 +106,41 @@ def test_fft4096_kernel_indices_and_image(hop, in_kind, round_frames, monkeypatc
             route = eng.kernel_route()
         want = lut.reshape(256, 4)[got[:, lo:hi].T[::-1]]
         if hop % 4 == 0:
-            assert route == "stft4096_kernel<image>:rgba + stft_mw_kernel<4096,single,marked> + colorize_marked_kernel", route
+            assert route == "stft4096_kernel<image,redo>:rgba", route
             assert img.shape == want.shape and np.array_equal(img, want)          # same arithmetic, same indices
         else:
             assert route == "stft_mw_kernel<4096,single>:u8 + colorize_kernel", route
             assert img.shape == want.shape and np.array_equal(img, want)
+
+
+def test_fft4096_image_rounds_of_64_frames():
+    """A recording long enough that the 4096-point image writer takes rounds of 64 frames (every workgroup gets at
+    least 16 of them): the image of a band equals the colour map applied to the index output of the same frames, the
+    indices of a few stretches of frames are within 1 LSB of the checker, and the last, partial round is written."""
+    n, hop = 4096, 256
+    cus = 256
+    frames = 64 * 16 * cus + 37
+    L = n + hop * (frames - 1) + 9
+    rng = np.random.default_rng(4096)
+    x = (rng.standard_normal(L) * 0.003).astype(np.float32)
+    t = np.arange(hop * 4000, dtype=np.float64)
+    call = (0.3 * np.sin(0.9 * t + 2e-6 * t * t)).astype(np.float32)
+    for start in (0, L // 3, L - call.size):       # three loud stretches, one at each end
+        x[start:start + call.size] += call
+    lo, hi = 161, 291
+    lut = (np.arange(1024, dtype=np.uint32) * 11 % 256).astype(np.uint8)
+    # (the index output takes whole groups of four bins; the image band starts and ends inside one)
+    with plugin_engine(n, hop, bin_lo=lo - 1, bin_hi=hi + 1) as e8, plugin_engine(n, hop, out_kind=F.OUT_RGBA8, bin_lo=lo, bin_hi=hi) as er:
+        er.set_colormap(lut)
+        idx, img = e8.stft(x)[:, 1:-1], er.stft(x)
+        assert er.kernel_route() == "stft4096_kernel<image,redo>:rgba"
+    assert idx.shape == (frames, hi - lo) and img.shape == (hi - lo, frames, 4)
+    assert np.array_equal(img, lut.reshape(256, 4)[idx.T[::-1]])
+    for f0 in (0, 3000, frames // 2, frames - 60):
+        ref = oracle.plugin_get_frequencies(x[f0 * hop:(f0 + 60) * hop + n], n, n - hop)[:, lo:hi]
+        assert ref.shape[0] >= 59
+        d = np.abs(idx[f0:f0 + ref.shape[0]].astype(np.int16) - ref.astype(np.int16))
+        assert np.minimum(d, 256 - d).max() <= 1, f0
 
 
 @pytest.mark.parametrize("n", [1024, 512])

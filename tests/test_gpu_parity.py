@@ -274,7 +274,7 @@ def test_colour_indices_within_one_lsb_under_near_full_scale_tones(n):
     assert route == {512: "stft512_kernel<table> + stft_mw_kernel<512,single,marked>",
                      1024: "stft1024_u8_kernel<table,redo>",
                      2048: "stft2048_kernel<table,redo>",
-                     4096: "stft4096_kernel + stft_mw_kernel<4096,single,marked>"}[n], route
+                     4096: "stft4096_kernel<redo>"}[n], route
 
 
 def test_plugin_accurate_twiddles_differ_from_recurrence_at_4096():
@@ -469,7 +469,7 @@ def test_kernel_route_is_visible_and_default_view_is_fast():
         assert eng.kernel_route() == "stft1024_rgba_kernel<roots>:rgba + stft_general_kernel<float>"   # + the wrapped last frame
     with plugin_engine(4096, 256, F.ARITH_FAST_F32, out_kind=F.OUT_RGBA8, bin_lo=160, bin_hi=1280) as eng:
         eng.stft(x)
-        assert eng.kernel_route() == "stft4096_kernel<image>:rgba + stft_mw_kernel<4096,single,marked> + colorize_marked_kernel"
+        assert eng.kernel_route() == "stft4096_kernel<image,redo>:rgba"
     with plugin_engine(256, 64, F.ARITH_FAST_F32) as eng:
         eng.stft(x)
         assert eng.kernel_route() == "stft_general_kernel<float>"
