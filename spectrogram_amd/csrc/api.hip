@@ -56,13 +56,13 @@ struct sono_ctx {
   bool pair_exact = false;  // StftParams::pair_exact
   double pair_asym = 0;     // StftParams::pair_asym
   bool pair_idx_ok = true;  // StftParams::pair_idx_ok
-  // Pairs of frames (1024 points) or a frame's even / odd samples (4096 points) under an asymmetric table: the kernels
-  // mark the loud units and a one-frame-per-transform launch recomputes those (StftParams::loud_flags)
-  bool loud_marks = false;
+  // Pairs of frames (512 / 1024 / 2048 points) or a frame's even / odd samples (4096 points) under an asymmetric table
+  // are safe only below a sample level: the kernels transform their loud units once more, one frame per transform
+  // (StftParams::loud_thr_raw)
+  bool loud_redo = false;
   bool split_ok = true;     // StftParams::split_ok
-  float loud_thr_raw = 0.0f, loud_thr_win = 0.0f;
-  uint8_t* d_loud = nullptr;   // kLoudFlagBytes of marks (512 points)
-  void* d_redo = nullptr;      // StftParams::redo_scratch (4096 points)
+  float loud_thr_raw = 0.0f;
+  void* d_redo = nullptr;   // StftParams::redo_scratch (4096 points)
   std::string route;        // kernels of the most recent transform call (sono_kernel_route)
   std::string err;
 };
@@ -104,13 +104,8 @@ static void* static_scratch_of(int dev) {
 }
 
 static thread_local const char* t_kernel = "";
-static thread_local bool t_marks = false;
 namespace sono {
-void note_kernel(const char* name) {
-  t_kernel = name;
-  t_marks = false;
-}
-void note_marking(bool marks) { t_marks = marks; }
+void note_kernel(const char* name) { t_kernel = name; }
 }
 
 // Frames that the feature fix-up pass can list per launch (4 MiB; beyond it the pass scans for the rest).
@@ -335,7 +330,7 @@ void sono_destroy(sono_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
-  void* bufs[] = {c->d_window, c->d_tw, c->d_tw_exact, c->d_claim, c->d_lut, c->d_fast, c->d_in, c->d_out, c->d_aux, c->d_fb_bin, c->d_fb_w, c->d_fb_packed, c->d_loud, c->d_redo};
+  void* bufs[] = {c->d_window, c->d_tw, c->d_tw_exact, c->d_claim, c->d_lut, c->d_fast, c->d_in, c->d_out, c->d_aux, c->d_fb_bin, c->d_fb_w, c->d_fb_packed, c->d_redo};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
   if (c->ev_start) (void)hipEventDestroy(c->ev_start);
@@ -493,10 +488,6 @@ static bool compute_mw_ok(const sono_ctx* c, bool with_filterbank = false) {
   return true;
 }
 
-// Marks of the loud units: one byte per group of four frames, indexed modulo the buffer (16.7 M frames before two groups
-// share a byte, which only ever marks more).
-constexpr uint64_t kLoudFlagBytes = (uint64_t)1 << 22;
-
 // Default size of the RGBA index-chunk buffer when the context cannot write the image from the transform kernel.
 constexpr uint64_t kDefaultChunkBytes = (uint64_t)32 << 20;
 constexpr uint64_t kMaxChunkBytes = (uint64_t)96 << 20;
@@ -510,7 +501,7 @@ static int refresh_routes(sono_ctx* c) {
   c->fb_mw_ok = c->d_fb_bin ? compute_mw_ok(c, true) : false;
   c->pair_asym = table_asymmetry(c);
   c->pair_exact = c->pair_asym <= 5e-7;
-  c->loud_marks = false;
+  c->loud_redo = false;
   c->split_ok = true;
   if (c->pair_exact) {
     c->pair_idx_ok = true;
@@ -521,10 +512,10 @@ static int refresh_routes(sono_ctx* c) {
     // window).  A colour index moves by less than one step while |X| is off by less than eps = 10^(step in dB / 20) - 1
     // of its value, and the smallest value that shows is the quantiser's floor; half of that is left to float32
     // rounding.  So pairs are safe outright if full-scale samples cannot reach the bound; safe with the loud units
-    // marked and recomputed one frame per transform if a plausible level can (the register kernels at 512 / 1024 / 2048
-    // points mark, and so does the 4096-point kernel, which splits a frame into even and odd samples and carries the
-    // defect of the 2048-point transform inside it twice); otherwise such a context transforms one frame at a time
-    // from the start.
+    // transformed once more, one frame per transform, if a plausible level can (the register kernels at 512 / 1024 /
+    // 2048 points do that themselves, and so does the 4096-point kernel, which splits a frame into even and odd
+    // samples and carries the defect of the 2048-point transform inside it twice); otherwise such a context transforms
+    // one frame at a time from the start.
     const uint32_t n = c->cfg.fft_n;
     const bool plugin = c->cfg.scale_mode == SONO_SCALE_PLUGIN_DB;
     const double eps = plugin ? std::pow(10.0, (double)c->cfg.range_db / (255.0 * 20.0)) - 1.0 : std::pow(10.0, 5.0 / 255.0) - 1.0;
@@ -537,35 +528,32 @@ static int refresh_routes(sono_ctx* c) {
     }
     double g_raw = 0, g_win = 0;
     pair_defect_gains(n, tc.data(), ts.data(), c->h_window.data(), &g_raw, &g_win);
-    double thr_raw = g_raw > 0 ? crit / g_raw : 1e30, thr_win = g_win > 0 ? crit / g_win : 1e30;
+    double thr_raw = g_raw > 0 ? crit / g_raw : 1e30;
     c->pair_idx_ok = thr_raw >= 1.0;
-    bool marks = !c->pair_idx_ok && (n == 512 || n == 1024 || n == 2048);
+    bool redo = !c->pair_idx_ok && (n == 512 || n == 1024 || n == 2048);
     if (n == 4096) {  // the kernel that splits a frame: the inner transform's table is the first eleven stages of this one
       std::vector<float> we(n / 2), wo(n / 2);
       for (uint32_t i = 0; i < n / 2; i++) {
         we[i] = c->h_window[2 * i];
         wo[i] = c->h_window[2 * i + 1];
       }
-      double ge = 0, go = 0, gw = 0, gw2 = 0;
+      double ge = 0, go = 0, gw = 0;
       pair_defect_gains(n / 2, tc.data(), ts.data(), we.data(), &ge, &gw);
-      pair_defect_gains(n / 2, tc.data(), ts.data(), wo.data(), &go, &gw2);
+      pair_defect_gains(n / 2, tc.data(), ts.data(), wo.data(), &go, &gw);
       const double g2 = 2.0 * (ge > go ? ge : go);  // X[k] = E[k] + w O[k]: both halves' errors add
       thr_raw = g2 > 0 ? crit / g2 : 1e30;
-      thr_win = gw > 0 ? crit / (2.0 * gw) : 1e30;
-      marks = thr_raw < 1.0;
-      c->split_ok = !marks;
+      redo = thr_raw < 1.0;
+      c->split_ok = !redo;
     }
     const bool index_out = c->cfg.out_kind == SONO_OUT_U8_INDEX || c->cfg.out_kind == SONO_OUT_RGBA8;
-    // (a filter bank: the 1024-point kernel alone applies it to pairs; the 1024-point kernels redo their loud units
-    // themselves and need no marks)
-    if (marks && index_out && thr_raw >= 0.02 && (!c->d_fb_bin || n == 1024) && c->cfg.arith == SONO_ARITH_FAST_F32) {
-      c->loud_marks = true;
+    // (a filter bank: the 1024-point kernel alone applies it to pairs; a threshold below a fiftieth of full scale: nearly
+    // every unit would be loud, one frame per transform from the start is cheaper)
+    if (redo && index_out && thr_raw >= 0.02 && (!c->d_fb_bin || n == 1024) && c->cfg.arith == SONO_ARITH_FAST_F32) {
+      c->loud_redo = true;
       c->loud_thr_raw = (float)thr_raw;
-      c->loud_thr_win = (float)thr_win;
-      if (n == 512 && !c->d_loud) HIP_TRY(c, hipMalloc((void**)&c->d_loud, kLoudFlagBytes));
       if (n == 4096 && !c->d_redo) HIP_TRY(c, hipMalloc(&c->d_redo, redo_scratch_bytes()));
     }
-    // (the 4096-point kernel without marks would be unsafe: see launch_range)
+    // (the 4096-point kernel without that would be unsafe: see fast4096_available)
   }
   const bool ragged_u8 = c->cfg.out_kind == SONO_OUT_U8_INDEX && ((c->bin_lo | c->bin_hi) & 3u) && (c->fast_mode || c->mw_ok);
   const bool fb_route = (c->fb_fast_mode || c->fb_mw_ok) && (c->cfg.out_kind == SONO_OUT_RGBA8 || c->cfg.out_kind == SONO_OUT_U8_INDEX);
@@ -614,48 +602,16 @@ static int launch_range(sono_ctx* c, const StftParams& q_in, const IndexScratch&
   const bool fb_fused = q_in.fb_bin && !exact && c->d_fb_packed && (fb_1024 || fb_mw) &&
                         (rgba || (q_in.out_kind == SONO_OUT_U8_INDEX && !((q_in.bin_lo | q_in.bin_hi | q_in.out_bins | q_in.out_bin0) & 3u)));
   StftParams q = q_in;
-  // An asymmetric table whose pairs (1024 points) or split frames (4096 points) are safe only below a sample level: the
-  // kernels mark the loud units and a one-frame-per-transform launch recomputes them (refresh_routes).
-  const bool loud = c->loud_marks && (q_in.n == 512 ? c->d_loud != nullptr : q_in.n == 4096 ? c->d_redo != nullptr : true) && !exact && q_in.nframes >= 16 &&
+  // An asymmetric table whose pairs (512 / 1024 / 2048 points) or split frames (4096 points) are safe only below a sample
+  // level: the kernels transform their loud units once more, one frame per transform (refresh_routes).
+  const bool loud = c->loud_redo && (q_in.n != 4096 || c->d_redo != nullptr) && !exact && q_in.nframes >= 16 &&
                     (q_in.out_kind == SONO_OUT_U8_INDEX || rgba) &&
                     (!q_in.fb_bin || (q_in.n == 1024 && fb_fused && fb_1024));  // (a filter bank: the 1024-point kernel alone)
   if (loud) {
-    // (the 1024-, 2048- and 4096-point kernels transform their loud units once more themselves)
-    if (q.n == 512) {
-      q.loud_flags = c->d_loud;
-      q.loud_mask = (uint32_t)(kLoudFlagBytes - 1);
-    }
     if (q.n == 4096) q.redo_scratch = c->d_redo;
     q.loud_thr_raw = c->loud_thr_raw;
-    q.loud_thr_win = c->loud_thr_win;
-    if (q.n != 4096) q.pair_idx_ok = 1;  // (4096 points: the pairing three-pass kernel stays off, the splitting kernel marks)
+    if (q.n != 4096) q.pair_idx_ok = 1;  // (4096 points: the pairing three-pass kernel stays off, the splitting kernel serves)
   }
-  // clears the marks of a launch's frames before it, and recomputes the marked units behind it
-  auto clear_marks = [&](const StftParams& u) -> int {
-    if (!u.loud_flags) return SONO_OK;
-    const uint64_t g0 = u.frame0 >> 2, g1 = (u.frame0 + u.nframes + 3) >> 2;
-    if (g1 - g0 + 1 >= kLoudFlagBytes) {
-      HIP_TRY(c, hipMemsetAsync(u.loud_flags, 0, kLoudFlagBytes, c->stream));
-    } else {
-      const uint64_t a = g0 & (kLoudFlagBytes - 1), b = g1 & (kLoudFlagBytes - 1);
-      if (a <= b) {
-        HIP_TRY(c, hipMemsetAsync(u.loud_flags + a, 0, b - a + 1, c->stream));
-      } else {
-        HIP_TRY(c, hipMemsetAsync(u.loud_flags + a, 0, kLoudFlagBytes - a, c->stream));
-        HIP_TRY(c, hipMemsetAsync(u.loud_flags, 0, b + 1, c->stream));
-      }
-    }
-    return SONO_OK;
-  };
-  auto redo_marked = [&](const StftParams& u) -> int {
-    if (!u.loud_flags || !t_marks) return SONO_OK;  // (a kernel that transforms one frame at a time marks nothing)
-    StftParams s2 = u;
-    s2.loud_only = 1;
-    int r2 = launch_stft_mw(s2, c->stream);
-    if (r2 != SONO_OK) return fail(c, r2 < 0 ? r2 : SONO_ERR_DEVICE, "launch of the pass over the marked frames failed");
-    note_route(c);
-    return SONO_OK;
-  };
   if (fb_fused) {
     q.fast_mode = fb_1024 ? c->fb_fast_mode : 0;
     q.mw_ok = fb_mw ? 1u : 0u;
@@ -669,7 +625,6 @@ static int launch_range(sono_ctx* c, const StftParams& q_in, const IndexScratch&
     if (!c->d_aux || c->d_aux_bytes < fast_rgba_scratch_bytes())
       return fail(c, SONO_ERR_ARG, "the context's image scratch is missing (tables changed without sono_set_tables?)");
     qq.tile_scratch = c->d_aux;
-    if (int rc = clear_marks(qq)) return rc;
     r = launch_stft_fast(qq, c->stream);
     if (r == 1) r = launch_stft_fast512(qq, c->stream);
     if (r == 1) r = launch_stft_fast2048(qq, c->stream);
@@ -677,37 +632,6 @@ static int launch_range(sono_ctx* c, const StftParams& q_in, const IndexScratch&
     if (r < 0) return fail(c, r, "kernel launch failed: %s", hipGetErrorString(hipGetLastError()));
     if (r == SONO_OK) {
       note_route(c, ":rgba");
-      if (!qq.loud_flags || !t_marks) return SONO_OK;
-      // The image writer marked its loud units: their colour indices are recomputed one frame per transform, a chunk
-      // of frames at a time into the context's scratch (free again behind the image writer), and the marked frames'
-      // columns are written over the image.
-      StftParams u = q;
-      u.out_kind = SONO_OUT_U8_INDEX;
-      u.bin_lo = q.bin_lo & ~3u;
-      u.bin_hi = (q.bin_hi + 3u) & ~3u;
-      u.out_bins = u.bin_hi - u.bin_lo;
-      u.out_bin0 = u.bin_lo;
-      u.lut = nullptr;
-      u.loud_only = 1;
-      u.out = c->d_aux;
-      const uint64_t nb = u.out_bins;
-      // frames per chunk, less 64 so that a last chunk of fewer than 64 frames can ride with the one before it
-      const uint64_t room = c->d_aux_bytes / nb / 64 * 64;  // (sparse rows, written and read once: the whole scratch)
-      if (room < 128) return fail(c, SONO_ERR_ARG, "the context's scratch is too small for the pass over the marked frames");
-      const uint64_t chunk = room - 64;
-      for (uint64_t f = 0; f < q.nframes; f += u.nframes) {
-        u.frame0 = q.frame0 + f;
-        u.nframes = (q.nframes - f < chunk + 64) ? q.nframes - f : chunk;
-        u.col0 = 0;
-        int r2 = launch_stft_mw(u, c->stream);
-        if (r2 != SONO_OK) return fail(c, r2 < 0 ? r2 : SONO_ERR_DEVICE, "launch of the pass over the marked frames failed");
-        note_route(c);
-        r2 = launch_colorize_marked((const uint8_t*)c->d_aux, u.nframes, (uint32_t)nb, u.bin_lo, q.bin_lo, q.bin_hi, q.row_of_bin0,
-                                    qq.lut, (uint8_t*)q.out, q.width, q.col0 + f, u.loud_flags, u.loud_mask, u.frame0, c->stream);
-        if (r2 != SONO_OK) return fail(c, r2, "colour-map launch over the marked frames failed");
-        sono::note_kernel("colorize_marked_kernel");
-        note_route(c);
-      }
       return SONO_OK;
     }
     // (r == 1: no image writer took the call after all, e.g. an output pointer that is not 4-byte aligned; the
@@ -742,24 +666,19 @@ static int launch_range(sono_ctx* c, const StftParams& q_in, const IndexScratch&
         u.col0 = 0;
         u.out = aux.ptr;
         r = 1;
-        bool marking = false;
         if (exact) {
           r = launch_stft_exact(u, c->stream);
           if (r == 1) r = launch_stft_general(u, true, c->stream);
         } else if (u.nframes >= 16) {
-          if (int rc = clear_marks(u)) return rc;
           if (fast) r = launch_stft_fast(u, c->stream);
           if (r == 1 && fast) r = launch_stft_fast512(u, c->stream);
           if (r == 1 && fast) r = launch_stft_fast2048(u, c->stream);
           if (r == 1 && fast) r = launch_stft_fast4096(u, c->stream);
           if (r == 1 && u.mw_ok) r = launch_stft_mw(u, c->stream);
-          marking = r == SONO_OK;
         }
         if (r == 1) r = launch_stft_general(u, exact, c->stream);
         if (r != SONO_OK) return fail(c, r, "kernel launch failed: %s", hipGetErrorString(hipGetLastError()));
         note_route(c, ":u8");
-        if (marking)
-          if (int rc = redo_marked(u)) return rc;
         r = launch_colorize((const uint8_t*)aux.ptr, u.nframes, (uint32_t)nb, u.bin_hi - q.bin_hi, q.bin_hi - q.bin_lo, q.lut,
                             (uint8_t*)q.out, q.width, q.col0 + f, c->stream);
         if (r != SONO_OK) return fail(c, r, "colorize launch failed");
@@ -845,21 +764,16 @@ static int launch_range(sono_ctx* c, const StftParams& q_in, const IndexScratch&
       w.col0 = 0;
       w.out = aux.ptr;
       r = 1;
-      bool marking = false;
       if (w.nframes >= 16) {
-        if (int rc = clear_marks(w)) return rc;
         if (fast) r = launch_stft_fast(w, c->stream);
         if (r == 1 && fast) r = launch_stft_fast512(w, c->stream);
         if (r == 1 && fast) r = launch_stft_fast2048(w, c->stream);
         if (r == 1 && fast) r = launch_stft_fast4096(w, c->stream);
         if (r == 1 && w.mw_ok) r = launch_stft_mw(w, c->stream);
-        marking = r == SONO_OK;
       }
       if (r == 1) r = launch_stft_general(w, false, c->stream);
       if (r != SONO_OK) return fail(c, r, "kernel launch failed: %s", hipGetErrorString(hipGetLastError()));
       note_route(c, ":band");
-      if (marking)
-        if (int rc = redo_marked(w)) return rc;
       uint8_t* dst = reinterpret_cast<uint8_t*>(q.out) + (q.col0 + f) * q.out_bins + (q.bin_lo - q.out_bin0);
       HIP_TRY(c, hipMemcpy2DAsync(dst, q.out_bins, reinterpret_cast<const uint8_t*>(aux.ptr) + (q.bin_lo - w.bin_lo), nb,
                                   q.bin_hi - q.bin_lo, w.nframes, hipMemcpyDeviceToDevice, c->stream));
@@ -881,15 +795,12 @@ static int launch_range(sono_ctx* c, const StftParams& q_in, const IndexScratch&
       listed = true;
     }
   }
-  if (!exact)
-    if (int rc = clear_marks(fq)) return rc;
   if (fast) r = launch_stft_fast(fq, c->stream);
   if (r != SONO_OK) listed = false;
   if (r == 1 && fast) r = launch_stft_fast512(fq, c->stream);
   if (r == 1 && fast) r = launch_stft_fast2048(fq, c->stream);
   if (r == 1 && fast) r = launch_stft_fast4096(fq, c->stream);
   if (r == 1 && q.mw_ok) r = launch_stft_mw(fq, c->stream);
-  const bool marking = !exact && r == SONO_OK && fq.loud_flags != nullptr;
   if (exact) r = launch_stft_exact(q, c->stream);
   // Feature records are integers that segmentation and species rules branch on, so they are the reference's in
   // both arithmetics: a float32 kernel marks the frames it cannot decide (two top bins too close, peak too close
@@ -907,8 +818,6 @@ static int launch_range(sono_ctx* c, const StftParams& q_in, const IndexScratch&
   if (r == 1) r = launch_stft_general(q, exact, c->stream);
   if (r != SONO_OK) return fail(c, r, "kernel launch failed: %s", hipGetErrorString(hipGetLastError()));
   note_route(c);
-  if (marking)
-    if (int rc = redo_marked(fq)) return rc;
   if (feat_fast) {
     StftParams u = q;
     u.twiddles = c->d_tw_exact;

@@ -632,7 +632,6 @@ int launch_stft_fast(const StftParams& p, void* stream_v) {
               : bank ? (tab ? (redo ? "stft1024_u8_kernel<table,bank,redo>" : "stft1024_u8_kernel<table,bank>") : "stft1024_u8_kernel<roots,bank>")
               : tab  ? (redo ? "stft1024_u8_kernel<table,redo>" : "stft1024_u8_kernel<table>")
                      : "stft1024_u8_kernel<roots>");
-  note_marking(false);  // (the flavours that pair frames under a table redo their loud units themselves)
   return hipGetLastError() == hipSuccess ? SONO_OK : SONO_ERR_DEVICE;
 }
 

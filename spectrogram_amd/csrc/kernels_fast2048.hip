@@ -820,7 +820,6 @@ int launch_stft_fast2048(const StftParams& p, void* stream_v) {
 #undef SONO_R2048
     // (redo: the kernel transforms its loud pairs once more, one frame at a time)
     note_kernel(tab ? (p.loud_thr_raw > 0.0f ? "stft2048_rgba_kernel<table,redo>" : "stft2048_rgba_kernel<table>") : "stft2048_rgba_kernel<roots>");
-    note_marking(false);
     return hipGetLastError() == hipSuccess ? SONO_OK : SONO_ERR_DEVICE;
   }
 #define SONO_L2048(PL, In, FE, H)                                                                               \
@@ -845,7 +844,6 @@ int launch_stft_fast2048(const StftParams& p, void* stream_v) {
 #undef SONO_L2048
   note_kernel(tab ? (p.out_kind == SONO_OUT_U8_INDEX && p.loud_thr_raw > 0.0f ? "stft2048_kernel<table,redo>" : "stft2048_kernel<table>")
                   : "stft2048_kernel<roots>");
-  note_marking(false);
   return hipGetLastError() == hipSuccess ? SONO_OK : SONO_ERR_DEVICE;
 }
 

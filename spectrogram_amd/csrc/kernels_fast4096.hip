@@ -449,7 +449,6 @@ int launch_stft_fast4096(const StftParams& p, void* stream_v) {
   // (redo: the kernel transforms the even and the odd samples of a loud frame apart)
   const bool redo = !p.split_ok;
   note_kernel(rgba ? (redo ? "stft4096_kernel<image,redo>" : "stft4096_kernel<image>") : redo ? "stft4096_kernel<redo>" : "stft4096_kernel");
-  note_marking(false);
   return hipGetLastError() == hipSuccess ? SONO_OK : SONO_ERR_DEVICE;
 }
 

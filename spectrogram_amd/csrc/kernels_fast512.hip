@@ -16,6 +16,8 @@
 // Outputs: [frame][bin] colour indices, or per-frame spectral peaks.
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include <cmath>
 #include <vector>
 
@@ -269,7 +271,12 @@ __global__ __launch_bounds__(kWaves * 64) void stft512_kernel(StftParams p, Fast
   const uint64_t iters = ((nunits + kWaves - 1) / kWaves + gridDim.x - 1) / gridDim.x;
   const uint64_t unit_end = ((uint64_t)vb + 1) * iters * kWaves < nunits ? ((uint64_t)vb + 1) * iters * kWaves : nunits;
 
-  for (uint64_t unit = (uint64_t)vb * iters * kWaves + wave; unit < unit_end; unit += kWaves) {
+  // REDO: under the context's table a unit too loud for the pair separation (StftParams::loud_thr_raw) is transformed one
+  // frame per transform: the loop body runs twice more, mode 1 = the frames fb, fb + 2 alone, mode 2 = fb + 1, fb + 3 alone
+  // (through the same code as the pairs).  Wave-uniform: the eight frames of a wavefront go together.
+  constexpr bool REDO = TABLE && !FEAT;
+  int mode = 0;
+  for (uint64_t unit = (uint64_t)vb * iters * kWaves + wave; unit < unit_end;) {
     const uint64_t f0 = unit * 8 + 4 * h;  // this half-wavefront's frames are f0 .. f0+3
     // The four frames transformed are fb .. fb+3: A = (fb, fb+1), B = (fb+2, fb+3).  At the end of the recording the
     // block is shifted back so that every load stays in bounds; frames before f0 (another half-wavefront's) and
@@ -283,12 +290,23 @@ __global__ __launch_bounds__(kWaves * 64) void stft512_kernel(StftParams p, Fast
         const float4 v = win_row[j];
         win[4 * j] = v.x; win[4 * j + 1] = v.y; win[4 * j + 2] = v.z; win[4 * j + 3] = v.w;
       }
-      const In* x0 = x + (p.frame0 + fb) * p.hop + l;
-      float loudest = 0.0f;  // TABLE: this lane's largest |sample| (the wavefront's eight frames are marked if it is loud)
+      // mode 2: the block starts one frame later and ends with frame fb + 3 (its samples come from the cache; nothing
+      // behind them is read, the frame after it may lie beyond the signal)
+      const bool second = REDO && mode == 2;
+      const In* x0 = x + (p.frame0 + fb + (second ? 1 : 0)) * p.hop + l;
+      if constexpr (REDO) asm volatile("" : "+v"(x0));  // (opaque: or samples already loaded are held in registers instead)
+      float loudest = 0.0f;  // TABLE: this lane's largest |sample|
       if constexpr (HOP32 > 0) {
         float raw[16 + 3 * HOP32];
 #pragma unroll
-        for (int a = 0; a < 16 + 3 * HOP32; ++a) raw[a] = ld<In>(x0, 32 * a);
+        for (int a = 0; a < 16 + 2 * HOP32; ++a) raw[a] = ld<In>(x0, 32 * a);
+        if (second) {
+#pragma unroll
+          for (int a = 16 + 2 * HOP32; a < 16 + 3 * HOP32; ++a) raw[a] = 0.0f;
+        } else {
+#pragma unroll
+          for (int a = 16 + 2 * HOP32; a < 16 + 3 * HOP32; ++a) raw[a] = ld<In>(x0, 32 * a);
+        }
         if constexpr (TABLE) loudest = max_abs(raw);
 #pragma unroll
         for (int a = 0; a < 16; ++a) {
@@ -299,9 +317,17 @@ __global__ __launch_bounds__(kWaves * 64) void stft512_kernel(StftParams p, Fast
         }
       } else {
         const In *x1 = x0 + p.hop, *x2 = x1 + p.hop, *x3 = x2 + p.hop;
+        float v3s[16];
+        if (second) {
+#pragma unroll
+          for (int a = 0; a < 16; ++a) v3s[a] = 0.0f;
+        } else {
+#pragma unroll
+          for (int a = 0; a < 16; ++a) v3s[a] = ld<In>(x3, 32 * a);
+        }
 #pragma unroll
         for (int a = 0; a < 16; ++a) {
-          const float v0 = ld<In>(x0, 32 * a), v1 = ld<In>(x1, 32 * a), v2 = ld<In>(x2, 32 * a), v3 = ld<In>(x3, 32 * a);
+          const float v0 = ld<In>(x0, 32 * a), v1 = ld<In>(x1, 32 * a), v2 = ld<In>(x2, 32 * a), v3 = v3s[a];
           if constexpr (TABLE)
             loudest = __builtin_fmaxf(loudest, __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(v0), __builtin_fabsf(v1)),
                                                                __builtin_fmaxf(__builtin_fabsf(v2), __builtin_fabsf(v3))));
@@ -311,8 +337,13 @@ __global__ __launch_bounds__(kWaves * 64) void stft512_kernel(StftParams p, Fast
           im[16 + brev4(a)] = v3 * win[a];
         }
       }
-      if constexpr (TABLE) {  // an asymmetric table: see StftParams::loud_flags
-        if (p.loud_flags) mark_loud(p, loudest > p.loud_thr_raw, p.frame0 + unit * 8, 8);
+      if constexpr (REDO) {
+        // (a NaN sample does not compare as loud and needs no second look: it poisons every bin either way)
+        if (mode == 0 && p.loud_thr_raw > 0.0f && __builtin_amdgcn_ballot_w64(loudest > p.loud_thr_raw) != 0) mode = 1;
+        if (mode != 0) {
+#pragma unroll
+          for (int a = 0; a < 32; ++a) im[a] = 0.0f;
+        }
       }
     }
     transform512<TABLE>(re, im, tw_lds, tw_flat, plane, l);
@@ -332,6 +363,10 @@ __global__ __launch_bounds__(kWaves * 64) void stft512_kernel(StftParams p, Fast
     // noise and the pair's cross-talk scale with; see feature_uncertain)
     const bool banded = p.bin_lo != 0 || p.bin_hi != 256;  // wave-uniform
     float seen[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    // ALONE (REDO, mode 1 / 2): every transform held one frame; its spectrum is Z itself, taken twice so that the
+    // quantiser sees the same factor 2 as the pair separation leaves; it is frame fb + 2q (mode 1) or fb + 2q + 1 (mode 2).
+    auto epilogue = [&](auto alone_c) __attribute__((always_inline)) {
+    constexpr bool ALONE = decltype(alone_c)::value;
 #pragma unroll
     for (int P = 0; P < 2; ++P) {
       epilogue_cells(P, re, im, cell, le);
@@ -343,14 +378,14 @@ __global__ __launch_bounds__(kWaves * 64) void stft512_kernel(StftParams p, Fast
         const float2* mr = cell + kMirrorBase + q * kMirrorStride + 4 * le;
         const float4 z01 = *reinterpret_cast<const float4*>(lr);
         const float4 z23 = *reinterpret_cast<const float4*>(lr + 2);
-        const float4 q01 = *reinterpret_cast<const float4*>(mr);
-        const float4 q23 = *reinterpret_cast<const float4*>(mr + 2);
+        const float4 q01 = ALONE ? make_float4(0, 0, 0, 0) : *reinterpret_cast<const float4*>(mr);
+        const float4 q23 = ALONE ? make_float4(0, 0, 0, 0) : *reinterpret_cast<const float4*>(mr + 2);
         uint32_t wa = 0, wb = 0;
         float pa[4] = {0, 0, 0, 0}, pb[4] = {0, 0, 0, 0};
         const bool in_band = k >= (int)p.bin_lo && k < (int)p.bin_hi;
 #define SONO_BIN(B, ZR, ZI, PR, PI)                                                              \
   {                                                                                              \
-    const float ar = (ZR) + (PR), ai = (ZI) - (PI);                                              \
+    const float ar = ALONE ? (ZR) + (ZR) : (ZR) + (PR), ai = ALONE ? (ZI) + (ZI) : (ZI) - (PI);  \
     const float br = (ZI) + (PI), bi = (PR) - (ZR);                                              \
     const float ma = __builtin_fmaf(ar, ar, ai * ai);                                            \
     const float mb = __builtin_fmaf(br, br, bi * bi);                                            \
@@ -387,12 +422,20 @@ __global__ __launch_bounds__(kWaves * 64) void stft512_kernel(StftParams p, Fast
           const uint64_t fa = fb + 2 * q;
           const uint64_t row_a = (p.col0 + fa) * p.out_bins, row_b = row_a + p.out_bins;
           const uint32_t col = k - p.out_bin0;
-          if (fa >= f0 && fa < p.nframes) *reinterpret_cast<uint32_t*>(out + row_a + col) = wa;
-          if (fa + 1 >= f0 && fa + 1 < p.nframes) *reinterpret_cast<uint32_t*>(out + row_b + col) = wb;
+          if constexpr (ALONE) {
+            const uint64_t fr = mode == 2 ? fa + 1 : fa;
+            if (fr >= f0 && fr < p.nframes) *reinterpret_cast<uint32_t*>(out + (mode == 2 ? row_b : row_a) + col) = wa;
+          } else {
+            if (fa >= f0 && fa < p.nframes) *reinterpret_cast<uint32_t*>(out + row_a + col) = wa;
+            if (fa + 1 >= f0 && fa + 1 < p.nframes) *reinterpret_cast<uint32_t*>(out + row_b + col) = wb;
+          }
         }
       }
       wave_sync();  // the buffer is rewritten by the next half / the next iteration's transpose
     }
+    };  // epilogue
+    if (REDO && mode != 0) epilogue(std::true_type{});
+    else epilogue(std::false_type{});
     if constexpr (FEAT) {
       // larger |X|^2 wins, equal values go to the lower bin
 #pragma unroll
@@ -416,6 +459,14 @@ __global__ __launch_bounds__(kWaves * 64) void stft512_kernel(StftParams p, Fast
         }
       }
     }
+    if constexpr (REDO) {
+      if (mode == 1) {
+        mode = 2;
+        continue;
+      }
+      mode = 0;
+    }
+    unit += kWaves;
   }
 }
 
@@ -541,26 +592,42 @@ __global__ __launch_bounds__(kWaves * 64) void stft512_rgba_kernel(StftParams p,
     for (int m = 0; m < 8; ++m)
       if (32 * m + 31 >= (int)p.bin_lo && 32 * m < (int)p.bin_hi) row[m * 32 * kP] = r[m];
   };
-  for (uint64_t it = 0; it < (rounds + 2) * kRIters; ++it) {
+  auto park8_or = [&](const uint32_t (&r)[8], uint64_t k, int fg, int bin0) {  // ... OR-ed onto the dwords there
+    constexpr int kD = Ring<kRF>::kDwords, kP = Ring<kRF>::kPitch;
+    int d = (int)(((uint64_t)(kRF / 4) * k) % kD) + fg;
+    d -= d >= kD ? kD : 0;
+    uint32_t* row = slot + bin0 * kP + d;
+#pragma unroll
+    for (int m = 0; m < 8; ++m)
+      if (32 * m + 31 >= (int)p.bin_lo && 32 * m < (int)p.bin_hi) row[m * 32 * kP] |= r[m];  // (this lane's own dwords)
+  };
+  // Under the context's table a unit too loud for the pair separation (StftParams::loud_thr_raw) is transformed one frame
+  // per transform: the iteration's transforms run twice, mode 1 = the first frames of the pairs alone, then mode 2 = the
+  // second frames alone (whose bytes are OR-ed onto the first ones').  Wave-uniform: the eight frames of a wavefront go
+  // together.  A NaN sample does not compare as loud and needs no second look (it poisons every bin either way).
+  int mode = 0;
+  for (uint64_t it = 0; it < (rounds + 2) * kRIters;) {
     const uint64_t round = it / kRIters;
     const int sub = (int)(it % kRIters);
     const uint64_t f0 = first_frame(it);
-    // iteration 1: every wavefront has read its parts 2, 3 of the round before (end of its iteration 0), so the slot may
-    // be overwritten from here on
-    if (sub == 1) __syncthreads();
-    // (the empty asm is a use of the loaded registers: the wait for them lands here, before the image stores)
+    if (!(TABLE && mode == 2)) {
+      // iteration 1: every wavefront has read its parts 2, 3 of the round before (end of its iteration 0), so the slot
+      // may be overwritten from here on
+      if (sub == 1) __syncthreads();
+      // (the empty asm is a use of the loaded registers: the wait for them lands here, before the image stores)
 #pragma unroll
-    for (int a = 0; a < kRaw; ++a) asm volatile("" : "+v"(raw[a]));
-    if (round > 0 && rg.f_lo < rg.f_hi) {
-      const uint64_t fround = rg.f_lo + (round - 1) * kRF;
-      flush_rows(fq[0], fround, 2 * sub);
-      flush_rows(fq[1], fround, 2 * sub + 1);
+      for (int a = 0; a < kRaw; ++a) asm volatile("" : "+v"(raw[a]));
+      if (round > 0 && rg.f_lo < rg.f_hi) {
+        const uint64_t fround = rg.f_lo + (round - 1) * kRF;
+        flush_rows(fq[0], fround, 2 * sub);
+        flush_rows(fq[1], fround, 2 * sub + 1);
+      }
     }
     // wave-uniform: does this wavefront have a frame in this iteration?
     const bool active = it < rounds * kRIters && rg.f_lo + 128 * it + 8 * wave < p.nframes;
     if (active) {
-      if constexpr (TABLE) {  // an asymmetric table: see StftParams::loud_flags
-        if (p.loud_flags) mark_loud(p, max_abs(raw) > p.loud_thr_raw, p.frame0 + rg.f_lo + 128 * it + 8 * wave, 8);
+      if constexpr (TABLE) {
+        if (mode == 0 && p.loud_thr_raw > 0.0f && __builtin_amdgcn_ballot_w64(max_abs(raw) > p.loud_thr_raw) != 0) mode = 1;
       }
       float re[32], im[32];
       {
@@ -576,6 +643,10 @@ __global__ __launch_bounds__(kWaves * 64) void stft512_rgba_kernel(StftParams p,
           im[brev4(a)] = raw[a + (HOP32 > 0 ? HOP32 : 16)] * win[a];
           re[16 + brev4(a)] = raw[a + (HOP32 > 0 ? 2 * HOP32 : 32)] * win[a];
           im[16 + brev4(a)] = raw[a + (HOP32 > 0 ? 3 * HOP32 : 48)] * win[a];
+        }
+        if (TABLE && mode != 0) {
+#pragma unroll
+          for (int a = 0; a < 32; ++a) im[a] = 0.0f;
         }
       }
       transform512<TABLE, true>(re, im, tw_lds, tw_flat, blk, l);  // register k2 = Z_g[k1 + 16*k2] in lane 16g + k1
@@ -598,6 +669,23 @@ __global__ __launch_bounds__(kWaves * 64) void stft512_rgba_kernel(StftParams p,
       unsigned char* wr0 = lane0 ? cb + 7 * 128 : cb + 8 * ke;
       const unsigned char* rd = cb + 8 * ((16 - ke) & 15);
       uint32_t w[16];
+      if (TABLE && mode != 0) {
+        // a frame alone: its spectrum is Z itself (no partner; the same factor 2 as the pair separation leaves); the
+        // other frame's byte stays 0 in this pass
+        if (mode == 1) {
+#pragma unroll
+          for (int k2 = 0; k2 < 16; ++k2) {
+            const float ar = re[k2] + re[k2], ai = im[k2] + im[k2];
+            w[k2] = put_index<PLUGIN, 0>(__builtin_fmaf(ar, ar, ai * ai), fs, 0u);
+          }
+        } else {
+#pragma unroll
+          for (int k2 = 0; k2 < 16; ++k2) {
+            const float ar = re[k2] + re[k2], ai = im[k2] + im[k2];
+            w[k2] = put_index<PLUGIN, 1>(__builtin_fmaf(ar, ar, ai * ai), fs, 0u);
+          }
+        }
+      } else {
 #pragma unroll
       for (int R = 0; R < 2; ++R) {
         const int r0 = 16 + 8 * R, rx = (24 + 8 * R) & 31;
@@ -617,6 +705,7 @@ __global__ __launch_bounds__(kWaves * 64) void stft512_rgba_kernel(StftParams p,
         }
         wave_sync();  // the block is rewritten by the next round / the next iteration's transpose
       }
+      }
       // the lanes of transform g hold the frames (fb + 2g, +1); after the swap lane (g, k1) holds all four frames of the
       // bins k1 + 16*(2m + g), m = 0..7, as one dword per bin: what a ring row takes.  At the end of the recording the
       // frames this lane owns start at byte `shift` of the dword.
@@ -628,10 +717,40 @@ __global__ __launch_bounds__(kWaves * 64) void stft512_rgba_kernel(StftParams p,
       }
       if (sub == 0) {
 #pragma unroll
-        for (int m = 0; m < 8; ++m) pend[m] = r8[m];
+        for (int m = 0; m < 8; ++m) pend[m] = (TABLE && mode == 2) ? pend[m] | r8[m] : r8[m];
+      } else if (TABLE && mode == 2) {
+        park8_or(r8, round, fg, ke + 16 * ge);  // (onto what the pass for the first frames left there)
       } else {
         park8(r8, round, fg, ke + 16 * ge);
       }
+    }
+    if constexpr (TABLE) {
+      if (mode == 1) {
+        // the first frames alone are done: the same unit once more for the second frames alone -- the block starts one
+        // frame later and ends with its fourth frame (samples from the cache; nothing behind them is read, the frame
+        // after it may lie beyond the signal)
+        const uint64_t fb = f0 + 4 <= p.nframes ? f0 : p.nframes - 4;
+        const In* x0 = x + (p.frame0 + fb + 1) * p.hop + l;
+        asm volatile("" : "+v"(x0));  // (opaque: or the samples already loaded for the pairs are kept in registers instead)
+        if constexpr (HOP32 > 0) {
+#pragma unroll
+          for (int a = 0; a < 16 + 2 * HOP32; ++a) raw[a] = ld<In>(x0, 32 * a);
+#pragma unroll
+          for (int a = 16 + 2 * HOP32; a < kRaw; ++a) raw[a] = 0.0f;
+        } else {
+          const In* x2 = x0 + 2 * (uint64_t)p.hop;
+#pragma unroll
+          for (int a = 0; a < 16; ++a) {
+            raw[a] = ld<In>(x0, 32 * a);
+            raw[16 + a] = 0.0f;
+            raw[32 + a] = ld<In>(x2, 32 * a);
+            raw[48 + a] = 0.0f;
+          }
+        }
+        mode = 2;
+        continue;
+      }
+      mode = 0;
     }
     if (sub == 0) {
       pend_active = active;
@@ -650,6 +769,7 @@ __global__ __launch_bounds__(kWaves * 64) void stft512_rgba_kernel(StftParams p,
       __syncthreads();
       if (round <= rounds) read_rows(fq, 0, round);
     }
+    ++it;
   }
 }
 
@@ -721,8 +841,8 @@ int launch_stft_fast512(const StftParams& p, void* stream_v) {
     else { if (i16) SONO_R512_H(false, int16_t); else SONO_R512_H(false, float); }
 #undef SONO_R512_H
 #undef SONO_R512
-    note_kernel(tab ? "stft512_rgba_kernel<table>" : "stft512_rgba_kernel<roots>");
-    note_marking(tab && p.loud_flags != nullptr);
+    // (redo: the kernel transforms its loud units once more, one frame per transform)
+    note_kernel(tab ? (p.loud_thr_raw > 0.0f ? "stft512_rgba_kernel<table,redo>" : "stft512_rgba_kernel<table>") : "stft512_rgba_kernel<roots>");
     return hipGetLastError() == hipSuccess ? SONO_OK : SONO_ERR_DEVICE;
   }
 #define SONO_L512(PL, In, FE, H, T)                                                                              \
@@ -745,8 +865,8 @@ int launch_stft_fast512(const StftParams& p, void* stream_v) {
   else { if (i16) SONO_L512_F(false, int16_t); else SONO_L512_F(false, float); }
 #undef SONO_L512_F
 #undef SONO_L512
-  note_kernel(tab ? "stft512_kernel<table>" : "stft512_kernel<roots>");
-  note_marking(tab && p.out_kind == SONO_OUT_U8_INDEX && p.loud_flags != nullptr);
+  note_kernel(tab ? (p.out_kind == SONO_OUT_U8_INDEX && p.loud_thr_raw > 0.0f ? "stft512_kernel<table,redo>" : "stft512_kernel<table>")
+                  : "stft512_kernel<roots>");
   return hipGetLastError() == hipSuccess ? SONO_OK : SONO_ERR_DEVICE;
 }
 

@@ -419,7 +419,6 @@ int launch_stft_fast_rgba(const StftParams& p, void* stream_v) {
 #undef SONO_LAUNCH_HOP
 #undef SONO_LAUNCH_T
   note_kernel(tab ? (p.loud_thr_raw > 0.0f ? "stft1024_rgba_kernel<table,redo>" : "stft1024_rgba_kernel<table>") : "stft1024_rgba_kernel<roots>");
-  note_marking(false);  // (under a table the kernel redoes its loud units itself)
   return hipGetLastError() == hipSuccess ? SONO_OK : SONO_ERR_DEVICE;
 }
 

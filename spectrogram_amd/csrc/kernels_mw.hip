@@ -26,7 +26,6 @@
 #include "sono_device.h"
 #include "sono_internal.h"
 #include "sono_launch.h"
-#include "sono_loud.h"
 
 namespace sono {
 namespace mw {
@@ -140,34 +139,7 @@ __global__ __launch_bounds__((1 << LOG2N) / 16 * G, 4) void stft_mw_kernel(StftP
   for (int a1 = 0; a1 < 16; ++a1) win[rev4(a1)] = p.window[t + TN * a1];
 
   const uint64_t npairs = SINGLE ? p.nframes : (p.nframes + 1) >> 1;  // transforms
-  // The launch behind a kernel that pairs or splits frames (p.loud_only): only marked units are transformed.  Every
-  // wavefront looks at the marks of its next 64 iterations at once (lane j at iteration j from here) and jumps to the
-  // first one that holds a marked frame of its own; the wavefronts of a transform wider than one wavefront own the
-  // same single frame and so take the same jumps.
-  constexpr int kPerWave = TN >= 64 ? 1 : 64 / TN;  // frames (groups) per wavefront
-  auto next_marked = [&](uint64_t base) -> uint64_t {
-    if constexpr (SINGLE && OUT == kOutU8) {
-      if (p.loud_only) {
-        const uint64_t step = (uint64_t)gridDim.x * G;
-        const uint64_t mine = TN >= 64 ? 0 : (uint64_t)(threadIdx.x >> 6) * kPerWave;  // this wavefront's first frame in an iteration
-        while (base < npairs) {
-          const uint64_t b = base + (uint64_t)(threadIdx.x & 63) * step;
-          bool m = false;
-          if (b + mine < npairs) {
-            const uint64_t fr = p.frame0 + b + mine;
-            m = p.loud_flags[(fr >> 2) & p.loud_mask] != 0;
-            if (kPerWave > 1 && b + mine + kPerWave - 1 < npairs) m = m || p.loud_flags[((fr + kPerWave - 1) >> 2) & p.loud_mask] != 0;
-          }
-          const uint64_t hit = __builtin_amdgcn_ballot_w64(m);
-          if (hit) return base + (uint64_t)__builtin_ctzll(hit) * step;
-          base += 64 * step;
-        }
-        return npairs;
-      }
-    }
-    return base;
-  };
-  for (uint64_t base = next_marked((uint64_t)blockIdx.x * G); base < npairs; base = next_marked(base + (uint64_t)gridDim.x * G)) {
+  for (uint64_t base = (uint64_t)blockIdx.x * G; base < npairs; base += (uint64_t)gridDim.x * G) {
     // every group of the workgroup goes through every iteration (the larger sizes meet at barriers); one
     // without a pair of its own repeats the last pair and stores nothing
     const bool active = base + grp < npairs;
@@ -431,15 +403,14 @@ bool mw_u8_available(const StftParams& p) {
 
 int launch_stft_mw(const StftParams& p, void* stream_v) {
   using namespace mw;
-  // the second launch behind a kernel that pairs or splits frames: one frame per transform, marked units only
-  const bool marked = p.loud_only && p.loud_flags && !p.fb_packed && p.out_kind == SONO_OUT_U8_INDEX;
   const bool u8 = p.out_kind == SONO_OUT_U8_INDEX, feat = p.out_kind == SONO_OUT_FEATURES;
   const bool flt = p.out_kind == SONO_OUT_F32_DB || p.out_kind == SONO_OUT_F32_MAG;
   if (!(u8 || feat || flt)) return 1;
   // one frame per transform where two would not do: float32 outputs under an asymmetric table (StftParams::pair_exact),
   // colour indices under a table whose cross-talk could show (StftParams::pair_idx_ok)
-  // (this kernel's pairing flavour marks nothing: where the caller relies on marks it transforms one frame at a time)
-  const bool single = (flt && !p.pair_exact) || (u8 && (!p.pair_idx_ok || p.loud_flags || p.loud_thr_raw > 0.0f)) || marked;
+  // (this kernel's pairing flavour does not redo loud pairs: where the caller relies on that, StftParams::loud_thr_raw, it
+  // transforms one frame at a time)
+  const bool single = (flt && !p.pair_exact) || (u8 && (!p.pair_idx_ok || p.loud_thr_raw > 0.0f));
   // a non-linear frequency scale: colour indices only, plugin quantiser
   const bool bank = p.fb_packed != nullptr;
   if (bank && (!u8 || p.scale_mode != SONO_SCALE_PLUGIN_DB)) return 1;
@@ -497,9 +468,7 @@ int launch_stft_mw(const StftParams& p, void* stream_v) {
 #undef SONO_MW_IN
 #undef SONO_MW_M
 #undef SONO_MW
-  if (marked)
-    note_kernel(p.n == 4096 ? "stft_mw_kernel<4096,single,marked>" : p.n == 2048 ? "stft_mw_kernel<2048,single,marked>" : "stft_mw_kernel<512,single,marked>");
-  else if (bank)
+  if (bank)
     note_kernel(single ? (p.n == 4096 ? "stft_mw_kernel<4096,single,bank>" : p.n == 2048 ? "stft_mw_kernel<2048,single,bank>" : "stft_mw_kernel<512,single,bank>")
                        : (p.n == 4096 ? "stft_mw_kernel<4096,bank>" : p.n == 2048 ? "stft_mw_kernel<2048,bank>" : "stft_mw_kernel<512,bank>"));
   else

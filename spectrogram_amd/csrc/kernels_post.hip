@@ -139,77 +139,6 @@ int launch_colorize(const uint8_t* frames, uint64_t ncols, uint32_t bins, uint32
   return hipGetLastError() == hipSuccess ? SONO_OK : SONO_ERR_DEVICE;
 }
 
-// The image columns of the frames that a one-frame-per-transform launch recomputed (StftParams::loud_flags): frames is
-// the [ncols][bins] uint8 chunk it wrote (rows of unmarked frames hold nothing), bins [bin_first, bin_first + bins) of
-// which [band_lo, band_hi) belong to the image; column c of the chunk is image column col0 + c and frame frame_base + c
-// of the call, whose group of four frames is marked or not.  A workgroup takes 64 columns x 64 bins through LDS (read
-// along bins, written along columns); a lane stores the four pixels of one marked group in one row, so neighbouring
-// marked groups make one run.
-__global__ __launch_bounds__(256) void colorize_marked_kernel(const uint8_t* __restrict__ frames, uint64_t ncols, uint32_t bins,
-                                                             uint32_t bin_first, uint32_t band_lo, uint32_t band_hi, int32_t row_of_bin0,
-                                                             const uint32_t* __restrict__ lut, uint32_t* __restrict__ rgba,
-                                                             uint64_t img_width, uint64_t col0, const uint8_t* __restrict__ flags,
-                                                             uint32_t mask, uint64_t frame_base) {
-  __shared__ __attribute__((aligned(16))) uint8_t tile[64 * 80];  // [column][bin], 16 bytes of pad per column
-  __shared__ uint8_t s_mark[64];                                  // is column c0 + i of a marked group?
-  const uint64_t c0 = (uint64_t)blockIdx.x * 64;
-  const uint32_t tid = threadIdx.x;
-  // thread t loads 16 bins of column t >> 2 if that column's group is marked; most workgroups find no mark and leave
-  const uint32_t lc = tid >> 2, lb = 16 * (tid & 3);
-  const bool marked = c0 + lc < ncols && flags[((frame_base + c0 + lc) >> 2) & mask] != 0;
-  if ((tid & 3) == 0) s_mark[lc] = marked ? 1 : 0;
-  if (!__syncthreads_or(marked ? 1 : 0)) return;
-  for (uint32_t b0 = 0; b0 < bins; b0 += 64) {  // tiles of 64 bins, relative to bin_first
-    if (marked) {
-      // (the chunk's rows are whole groups of four bins and start on 4-byte boundaries)
-      const uint32_t* src = reinterpret_cast<const uint32_t*>(frames + (c0 + lc) * bins + b0 + lb);
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-        *reinterpret_cast<uint32_t*>(tile + lc * 80 + lb + 4 * j) = (b0 + lb + 4 * j < bins) ? src[j] : 0u;
-    }
-    __syncthreads();
-    // cell = (group of four columns, bin): 16 groups x 64 bins
-    for (uint32_t cell = tid; cell < 16 * 64; cell += 256) {
-      const uint32_t g = cell & 15, e = cell >> 4;
-      const uint32_t bin = bin_first + b0 + e;
-      if (b0 + e >= bins || bin < band_lo || bin >= band_hi) continue;
-      const uint64_t c = c0 + 4 * g;
-      const uint32_t m4 = *reinterpret_cast<const uint32_t*>(s_mark + 4 * g);  // (a group of four frames may straddle these four columns)
-      if (c >= ncols || m4 == 0) continue;
-      uint32_t* dst = rgba + (int64_t)(row_of_bin0 - (int32_t)bin) * (int64_t)img_width + (int64_t)(col0 + c);
-      uint32_t px[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const uint32_t idx = tile[(4 * g + j) * 80 + e];
-        px[j] = lut ? lut[idx] : (idx | (idx << 8) | (idx << 16) | 0xff000000u);
-      }
-      if (m4 == 0x01010101u) {  // (an s_mark byte is only set for a column inside the chunk)
-        typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
-        u32x4_a4 v;
-        v.x = px[0]; v.y = px[1]; v.z = px[2]; v.w = px[3];
-        *reinterpret_cast<u32x4_a4*>(dst) = v;
-      } else {
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          if ((m4 >> (8 * j)) & 1u) dst[j] = px[j];
-      }
-    }
-    __syncthreads();
-  }
-}
-
-int launch_colorize_marked(const uint8_t* frames, uint64_t ncols, uint32_t bins, uint32_t bin_first, uint32_t band_lo, uint32_t band_hi,
-                           int32_t row_of_bin0, const uint32_t* lut, uint8_t* rgba, uint64_t img_width, uint64_t col0,
-                           const uint8_t* flags, uint32_t mask, uint64_t frame_base, void* stream_v) {
-  if (ncols == 0 || bins == 0) return SONO_OK;
-  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_v);
-  const uint64_t gx = (ncols + 63) / 64;
-  if (gx > 0x7fffffffull) return SONO_ERR_ARG;
-  hipLaunchKernelGGL(colorize_marked_kernel, dim3((uint32_t)gx), dim3(256), 0, stream, frames, ncols, bins, bin_first, band_lo,
-                     band_hi, row_of_bin0, lut, reinterpret_cast<uint32_t*>(rgba), img_width, col0, flags, mask, frame_base);
-  return hipGetLastError() == hipSuccess ? SONO_OK : SONO_ERR_DEVICE;
-}
-
 // ------------------------------------------------------------------------------------------
 // The canvas step of drawSpectrogram, spectrogram.esm.js:357-361,377-381: the cropped rows
 // [sy, sy + sh) of the flipped LUT image are stretched over canvas rows [dy, dy + dh) of a

@@ -66,14 +66,9 @@ struct StftParams {
   // Two frames per transform under a twiddle table that is not conjugate-symmetric (the plugin's recurrence factors): a
   // frame's spectrum picks up a trace of its partner's and of its own mirror image, bounded by pair_defect_gains() times
   // the largest sample.  Where that bound could move a colour index by a whole step, the kernels that pair frames (or
-  // split one frame into its even and odd samples) mark the loud units -- one byte per group of four frames,
-  // loud_flags[(frame >> 2) & loud_mask] -- and a second launch of a one-frame-per-transform kernel (loud_only != 0)
-  // recomputes just those.  loud_flags == nullptr: nothing to mark (symmetric table, or the bound is harmless).
-  uint8_t* loud_flags;
-  uint32_t loud_mask;
-  float loud_thr_raw;     // a lane's largest |sample| above this marks the unit
-  float loud_thr_win;     // ... or its largest |sample * window| above this (kernels that keep no raw samples)
-  uint32_t loud_only;     // the second launch: units without a mark are skipped
+  // split one frame into its even and odd samples) transform a loud unit once more, one real frame per transform, whose
+  // spectrum is the reference's own transform of that frame.  0: nothing to redo (symmetric table, or the bound is harmless).
+  float loud_thr_raw;     // a lane's largest |sample| above this makes its wavefront's unit a loud one
   uint32_t split_ok;      // 4096 points: a frame may be transformed as its even and odd samples in one complex frame
                           // whatever its level (symmetric table, or a display floor its defect cannot reach)
   void* redo_scratch;     // device, 4096 points under a table whose split is not safe at every level: 16 KiB per wavefront of
@@ -83,8 +78,6 @@ struct StftParams {
 
 // Every launch_* function reports the kernel it enqueued (a static string), for sono_kernel_route.
 void note_kernel(const char* name);
-// ... and whether that kernel marks loud units in StftParams::loud_flags (a launch of one that does not needs no second pass).
-void note_marking(bool marks);
 
 // kernels_general.hip: table-driven radix-2 dataflow, any power-of-two size, both arithmetics.
 int launch_stft_general(const StftParams& p, bool exact_f64, void* hip_stream);
@@ -127,10 +120,6 @@ int launch_resample(const uint8_t* in, uint64_t in_frames, uint32_t bins, uint64
                     uint8_t* out, void* hip_stream);
 int launch_colorize(const uint8_t* frames, uint64_t ncols, uint32_t bins, uint32_t row0, uint32_t rows,
                     const uint32_t* lut, uint8_t* rgba, uint64_t img_width, uint64_t col0, void* hip_stream);
-// kernels_post.hip: the image columns of the marked frames of a chunk (StftParams::loud_flags) from their colour indices.
-int launch_colorize_marked(const uint8_t* frames, uint64_t ncols, uint32_t bins, uint32_t bin_first, uint32_t band_lo, uint32_t band_hi,
-                           int32_t row_of_bin0, const uint32_t* lut, uint8_t* rgba, uint64_t img_width, uint64_t col0,
-                           const uint8_t* flags, uint32_t mask, uint64_t frame_base, void* hip_stream);
 int launch_canvas_draw(const uint8_t* frames, uint64_t width, uint32_t bins, int64_t sy, int64_t sh, double dy, double dh,
                        uint32_t height, uint32_t background, const uint32_t* lut, uint8_t* canvas, void* hip_stream);
 // True when launch_stft_fast has a kernel for this size / layout with uint8 output.

@@ -251,12 +251,12 @@ def test_float32_db_bounds_down_to_the_display_floor(n):
 
 @pytest.mark.parametrize("n", [512, 1024, 2048, 4096])
 def test_colour_indices_within_one_lsb_under_near_full_scale_tones(n):
-    """The case that needs the one-frame-per-transform launch: a tone near full scale over a noise floor at the bottom of
+    """The case that needs one frame per transform: a tone near full scale over a noise floor at the bottom of
     the display range.  Transformed two frames at a time (or, at 4096 points, as even and odd samples) under the
     plugin's recurrence factors, such frames came out 2 LSB off the reference in about one pixel in 10^5 -- the bins
     within a few dB of the -100 dB floor that sit where the table's Hermitian defect puts the tone's image.  With the
-    loud units marked and recomputed one frame per transform every pixel is within 1 LSB, for random tone frequencies,
-    phases, levels and floors."""
+    loud units transformed once more, one frame per transform, inside the same kernel (<...,redo>) every pixel is within
+    1 LSB, for random tone frequencies, phases, levels and floors."""
     hop = n // 4
     rng = np.random.default_rng(n + 1)
     L = n + hop * 31 + 1
@@ -271,7 +271,7 @@ def test_colour_indices_within_one_lsb_under_near_full_scale_tones(n):
             d = cyc_diff(eng.stft(x), ref)
             assert d.max() <= 1 and (d != 0).mean() < 0.02, (n, trial, f, amp, noise, int((d > 1).sum()))
         route = eng.kernel_route()
-    assert route == {512: "stft512_kernel<table> + stft_mw_kernel<512,single,marked>",
+    assert route == {512: "stft512_kernel<table,redo>",
                      1024: "stft1024_u8_kernel<table,redo>",
                      2048: "stft2048_kernel<table,redo>",
                      4096: "stft4096_kernel<redo>"}[n], route
@@ -510,8 +510,8 @@ def test_one_frame_per_transform_where_pairing_would_leak():
     want = 20.0 * np.log10(np.maximum(mags.astype(np.float64), 1e-12))
     near = mags > mags.max(axis=1, keepdims=True) * 10 ** (-75 / 20)
     assert np.abs(db - want)[near].max() <= 0.01
-    # the other sizes: the register kernels mark as well and the three-pass kernel recomputes (2048 points, rectangular
-    # window); float32 dB comes from its one-frame-per-transform flavour (512 points)
+    # the other sizes: the register kernels redo their loud units as well (2048 points, rectangular window); float32 dB
+    # comes from the three-pass kernel's one-frame-per-transform flavour (512 points)
     y = x[:2048 + 512 * 300 + 1]
     ref = oracle.plugin_get_frequencies(y, 2048, 1536, window="rectangular")
     with plugin_engine(2048, 512, F.ARITH_FAST_F32, window="rectangular") as eng:
@@ -531,8 +531,8 @@ def test_one_frame_per_transform_where_pairing_would_leak():
 @pytest.mark.parametrize("hop,frames", [(256, 16), (256, 17), (512, 33), (100, 130), (333, 67), (768, 35)])
 @pytest.mark.parametrize("i16", [False, True])
 def test_one_frame_and_filter_bank_flavours_over_hops_inputs_and_lengths(flavour, hop, frames, i16):
-    """The 1024-point index kernel's one-frame-per-transform flavour -- as the launch that recomputes the units the
-    pairing kernel marked (this signal is loud throughout, so all of them), and with the filter bank (mel) -- over hops
+    """The 1024-point index kernel's one-frame-per-transform passes -- inside the pairing kernel, for the units too loud
+    for the pair separation (this signal is loud throughout, so all of them), and with the filter bank (mel) -- over hops
     with and without the shared sample run (multiples of 32 or not), float32 and int16 samples, frame counts from the
     smallest the kernel takes (16) over odd counts to a few rounds of the grid; a band of whole groups of four bins.
     Within 1 LSB of the checker."""
