@@ -30,6 +30,11 @@
 namespace sono {
 namespace fast2048 {
 
+#ifndef SONO_SYNC_ITERS_2048
+#define SONO_SYNC_ITERS_2048 1
+#endif
+constexpr int kSyncIters = SONO_SYNC_ITERS_2048;  // index kernel: iterations between two barriers of its wavefronts
+
 constexpr int kWaves = 16;                          // wavefronts per workgroup (one workgroup per CU): 32 frames per iteration
 constexpr int kPlaneStride = 68;                    // floats per transpose row (64 + 4: rows stay 16-B aligned)
 constexpr int kBufBytes = 32 * kPlaneStride * 4;    // 8704 per wavefront
@@ -362,7 +367,16 @@ __global__ __launch_bounds__(kWaves * 64) void stft2048_kernel(StftParams p, Fas
   // frame at a time: the loop body runs twice more, mode 1 = frame fb alone, mode 2 = frame fb + 1 alone.
   constexpr bool REDO = TABLE && !FEAT;
   int mode = 0;
-  for (uint64_t unit = (uint64_t)vb * iters * kWaves + wave; unit < unit_end;) {
+  // every wavefront goes through all `iters` iterations, with or without a pair of its own, and they meet at a barrier
+  // every kSyncIters of them: the samples neighbouring pairs share are then still in the caches when the next wavefront
+  // asks for them (left alone the wavefronts drift apart and fetch them from memory again)
+  for (uint64_t itn = 0; itn < iters;) {
+    const uint64_t unit = ((uint64_t)vb * iters + itn) * kWaves + wave;
+    if (mode == 0 && itn != 0 && itn % kSyncIters == 0) __syncthreads();
+    if (unit >= unit_end) {
+      ++itn;
+      continue;
+    }
     const uint64_t f0 = unit * 2;
     // the frames transformed are fb, fb + 1; an odd last frame is the second of the pair before it (frames before f0
     // are another wavefront's and are not stored)
@@ -543,7 +557,7 @@ __global__ __launch_bounds__(kWaves * 64) void stft2048_kernel(StftParams p, Fas
       }
       mode = 0;
     }
-    unit += kWaves;
+    ++itn;
   }
 }
 

@@ -36,6 +36,10 @@ namespace fast4096 {
 using namespace fast1024;
 
 constexpr int kWaves = 16;
+#ifndef SONO_SYNC_ITERS_4096
+#define SONO_SYNC_ITERS_4096 4
+#endif
+constexpr int kSyncIters = SONO_SYNC_ITERS_4096;
 constexpr int kTwBytes = 32 * 64 * 8;   // factors of the stages T <= 1024, [63 rows + 1][32] float2 (see the fill loop)
 constexpr int kLastBytes = 2048 * 8;    // factors w_k of the last stage
 constexpr int kWinBytes = 4096 * 4;
@@ -198,6 +202,11 @@ __global__ __launch_bounds__(kWaves * 64) void stft4096_kernel(StftParams p, Fas
     const int i = (int)(it % kRoundIters);
     const uint64_t f = round < rounds ? (round * gridDim.x + vb) * kRoundFrames + kWaves * i + wave : p.nframes;
     const bool active = f < p.nframes;  // wave-uniform
+    // (the index flavour has no barriers of its own: its wavefronts meet here every kSyncIters iterations, so that the
+    // samples neighbouring frames share are still in the caches when the next wavefront asks for them)
+    if constexpr (!RGBA) {
+      if (mode == 0 && it != 0 && it % kSyncIters == 0) __syncthreads();
+    }
     float4 raw[16];
     {
       const int v = lane & 31, u = lane >> 5;

@@ -32,6 +32,10 @@ namespace sono {
 namespace fast512 {
 
 constexpr int kWaves = 16;                          // wavefronts per workgroup (one workgroup per CU): 128 frames per iteration
+#ifndef SONO_SYNC_ITERS_512
+#define SONO_SYNC_ITERS_512 4
+#endif
+constexpr int kSyncIters = SONO_SYNC_ITERS_512;     // index kernel: iterations between two barriers of its wavefronts
 constexpr int kPlaneStride = 36;                    // floats per transpose row (rows 16-B aligned, b128 reads conflict-free)
 constexpr int kFftBufBytes = 32 * kPlaneStride * 4; // 4608 per half-wavefront
 // epilogue half P, float2 cells: Z_g[128P + j] at g*128 + j (j < 128), Z_g[512 - 128P - j] at 256 + g*130 + j (j <= 128)
@@ -276,7 +280,16 @@ __global__ __launch_bounds__(kWaves * 64) void stft512_kernel(StftParams p, Fast
   // (through the same code as the pairs).  Wave-uniform: the eight frames of a wavefront go together.
   constexpr bool REDO = TABLE && !FEAT;
   int mode = 0;
-  for (uint64_t unit = (uint64_t)vb * iters * kWaves + wave; unit < unit_end;) {
+  // every wavefront goes through all `iters` iterations, with or without frames of its own, and they meet at a barrier
+  // every kSyncIters of them: the samples neighbouring units share are then still in the caches when the next wavefront
+  // asks for them (left alone the wavefronts drift apart and fetch them from memory again)
+  for (uint64_t itn = 0; itn < iters;) {
+    const uint64_t unit = ((uint64_t)vb * iters + itn) * kWaves + wave;
+    if (mode == 0 && itn != 0 && itn % kSyncIters == 0) __syncthreads();
+    if (unit >= unit_end) {
+      ++itn;
+      continue;
+    }
     const uint64_t f0 = unit * 8 + 4 * h;  // this half-wavefront's frames are f0 .. f0+3
     // The four frames transformed are fb .. fb+3: A = (fb, fb+1), B = (fb+2, fb+3).  At the end of the recording the
     // block is shifted back so that every load stays in bounds; frames before f0 (another half-wavefront's) and
@@ -466,7 +479,7 @@ __global__ __launch_bounds__(kWaves * 64) void stft512_kernel(StftParams p, Fast
       }
       mode = 0;
     }
-    unit += kWaves;
+    ++itn;
   }
 }
 
