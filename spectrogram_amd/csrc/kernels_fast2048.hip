@@ -747,7 +747,10 @@ __global__ __launch_bounds__(kWaves * 64) void stft2048_rgba_kernel(StftParams p
       mode = 0;
     }
     fetch(first_frame(it + 1));
-    if (i == kRIters - 1) __syncthreads();  // this round's slot is complete and everyone is done reading the other one
+    // this round's slot is complete and everyone is done reading the other one.  (The flavour with exact roots meets after
+    // every iteration: measured 5 % faster, its wavefronts share more of their samples through the caches that way; under a
+    // table, where a loud pair makes its wavefront late, 1 % slower.)
+    if (i == kRIters - 1 || !TABLE) __syncthreads();
     const uint64_t nround = (it + 1) / kRIters;
     if (nround > 0 && nround <= rounds) {
       const int ni = (int)((it + 1) % kRIters);
