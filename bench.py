@@ -9,7 +9,7 @@ RGBA ImageData layout) over the whole recording.  `--out u8` stops at the colour
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--out u8|rgba] [--seconds S] [--files F]
 
-The same line also carries (`files`) the per-file batch of BASELINE's third configuration -- 5 s x 500 kHz int16
+The same line also carries (`files`) the per-file batch of the baseline's third configuration -- 5 s x 500 kHz int16
 recordings from host memory to host memory, sharded over the ranks by `sharding.assign_files`, each rank's share
 through the overlapped `FilePipeline`, per-file checksums gathered on rank 0 -- and (`variants.node_host_*`) the
 headline workload driven through the Node.js addon (node/bench.js).
@@ -116,7 +116,7 @@ def main():
     ap.add_argument("--no-variants", action="store_true")
     ap.add_argument("--files", type=int, default=-1,
                     help="per-file batch: number of 5 s x 500 kHz int16 files over all ranks (-1: 1250 per rank, which on "
-                         "8 GPUs is BASELINE's 10000; 0: skip)")
+                         "8 GPUs is the baseline's 10000; 0: skip)")
     ap.add_argument("--rehearse", action="store_true",
                     help="multi-rank dry run on a box with one GPU: every rank uses cuda:0")
     args = ap.parse_args()
@@ -206,7 +206,7 @@ def main():
         wall = float(t.item())
     value = world * L * args.steps / wall / 1e6
 
-    # ---- per-file batch (BASELINE configs[2]): host memory -> host memory, files sharded over the ranks
+    # ---- per-file batch (the baseline's third configuration): host memory -> host memory, files sharded over the ranks
     files_res = None
     n_files = 1250 * world if args.files < 0 else args.files
     if n_files > 0:

@@ -87,9 +87,10 @@ typedef enum sono_arith {
                               Under the plugin's recurrence twiddles (not conjugate-symmetric) two frames that
                               share a transform separate only up to the table's Hermitian defect; the library
                               bounds it per context (exact operator norm for the table and window) and, where a
-                              loud frame could move an index near the floor by a whole step, recomputes the
-                              loud frames one per transform behind the fast kernel (sono_kernel_route shows
-                              the extra launches), so the 1 LSB holds for every input.
+                              loud frame could move an index near the floor by a whole step, the kernels
+                              transform the loud frames once more, one frame per transform, inside the same
+                              launch (sono_kernel_route names such a kernel <...,redo>), so the 1 LSB holds
+                              for every input.
                               SONO_OUT_F32_DB: within 0.01 dB of the reference's own arithmetic for every
                               bin above that floor that lies within 80 dB of its frame's largest bin, and
                               within 0.04 dB for the bins 80..95 dB below it (measured worst case 0.026 dB

@@ -44,9 +44,9 @@ struct StftParams {
                           // for colour indices and peaks but not for float32 outputs held to 0.01 dB
   double pair_asym;       // that largest deviation from conjugate symmetry itself (0 for exact roots): a bin of one frame of a
                           // pair carries this fraction of the other frame's value at the same bin
-  uint32_t pair_idx_ok;   // colour indices and images may come from a kernel that transforms two frames at once: the largest
-                          // trace a frame can leave in its partner (pair_asym times a full-scale tone under this window)
-                          // stays below the quantiser's floor, so silence beside a burst stays silence
+  uint32_t pair_idx_ok;   // colour indices and images may come from a kernel that transforms two frames at once: either the
+                          // table's Hermitian defect cannot move an index by a step even for full-scale samples, or the
+                          // kernel transforms loud units once more, one frame per transform (loud_thr_raw below)
   const int32_t* fb_bin;  // device: non-linear frequency scale, first tap of output bin i (n/2 entries), or nullptr = linear
   const double* fb_w0;    // device: weight of bin fb_bin[i]
   const double* fb_w1;    // device: weight of bin fb_bin[i] + 1
