@@ -510,8 +510,8 @@ static int refresh_routes(sono_ctx* c) {
     // frame separate only up to the table's Hermitian defect: a bin is off by at most g times the largest sample of
     // the pair (pair_defect_gains: the exact operator norm for this table, as the kernels hold it in float32, and this
     // window).  A colour index moves by less than one step while |X| is off by less than eps = 10^(step in dB / 20) - 1
-    // of its value, and the smallest value that shows is the quantiser's floor; half of that is left to float32
-    // rounding.  So pairs are safe outright if full-scale samples cannot reach the bound; safe with the loud units
+    // of its value, and the smallest value that shows is the quantiser's floor; float32 rounding gets its share of that
+    // step first (below).  So pairs are safe outright if full-scale samples cannot reach the bound; safe with the loud units
     // transformed once more, one frame per transform, if a plausible level can (the register kernels at 512 / 1024 /
     // 2048 points do that themselves, and so does the 4096-point kernel, which splits a frame into even and odd
     // samples and carries the defect of the 2048-point transform inside it twice); otherwise such a context transforms
@@ -520,7 +520,12 @@ static int refresh_routes(sono_ctx* c) {
     const bool plugin = c->cfg.scale_mode == SONO_SCALE_PLUGIN_DB;
     const double eps = plugin ? std::pow(10.0, (double)c->cfg.range_db / (255.0 * 20.0)) - 1.0 : std::pow(10.0, 5.0 / 255.0) - 1.0;
     const double floor_mag = plugin ? 0.5 * (double)n * std::pow(10.0, -((double)c->cfg.gain_db + (double)c->cfg.range_db) / 20.0) : 1.0;
-    const double crit = 0.5 * eps * floor_mag;
+    // ... less what float32 rounding may take of the step: the float32 kernels are within 0.04 dB of the reference at a
+    // bin 95 dB below its frame's largest (the asserted bound; measured 0.026), i.e. within 8.2e-8 of that largest value,
+    // which for samples up to full scale is at most the window's sum; and 5 % of the step in reserve.
+    double wsum = 0.0;
+    for (uint32_t i = 0; i < n; i++) wsum += std::fabs((double)c->h_window[i]);
+    const double crit = 0.95 * eps * floor_mag - 8.2e-8 * wsum;  // (<= 0: no level is safe, one frame per transform throughout)
     std::vector<double> tc(n), ts(n);
     for (uint32_t i = 0; i + 1 < n; i++) {
       tc[i] = (double)(float)c->h_cos[i];
@@ -528,7 +533,7 @@ static int refresh_routes(sono_ctx* c) {
     }
     double g_raw = 0, g_win = 0;
     pair_defect_gains(n, tc.data(), ts.data(), c->h_window.data(), &g_raw, &g_win);
-    double thr_raw = g_raw > 0 ? crit / g_raw : 1e30;
+    double thr_raw = crit <= 0 ? 0.0 : g_raw > 0 ? crit / g_raw : 1e30;
     c->pair_idx_ok = thr_raw >= 1.0;
     bool redo = !c->pair_idx_ok && (n == 512 || n == 1024 || n == 2048);
     if (n == 4096) {  // the kernel that splits a frame: the inner transform's table is the first eleven stages of this one
@@ -541,7 +546,7 @@ static int refresh_routes(sono_ctx* c) {
       pair_defect_gains(n / 2, tc.data(), ts.data(), we.data(), &ge, &gw);
       pair_defect_gains(n / 2, tc.data(), ts.data(), wo.data(), &go, &gw);
       const double g2 = 2.0 * (ge > go ? ge : go);  // X[k] = E[k] + w O[k]: both halves' errors add
-      thr_raw = g2 > 0 ? crit / g2 : 1e30;
+      thr_raw = crit <= 0 ? 0.0 : g2 > 0 ? crit / g2 : 1e30;
       redo = thr_raw < 1.0;
       c->split_ok = !redo;
     }
