@@ -331,6 +331,8 @@ def main():
             torch.cuda.synchronize()
             result["roofline"][key] = round(nbytes * 5 / (e0.elapsed_time(e1) * 1e-3) / 1e9, 1)
         del y
+        # the kernel's algorithmic rate against what this box's memory system does for a linear read + write mix
+        result["roofline"]["frac_of_measured_copy"] = round(result["roofline"]["achieved"] / result["roofline"]["measured_copy_gbps"], 4)
 
     if rank == 0 and world == 1:
         # The vector-ALU roofline beside the HBM one: at hop = N/4 the transform is ~200 flop per sample over 6-12
