@@ -123,13 +123,13 @@ __global__ __launch_bounds__(kCompactThreads) void feature_marks_compact_kernel(
     if (at + i < capacity) q[kQueueHeader + at + i] = s_list[i];
 }
 
-// FIXUP (1024 points): `p.out` is a SONO_OUT_FEATURES output of a float32 kernel; only the records it marked
-// (reserved[0] != 0) are recomputed, each wavefront scanning blocks of 64 records and taking the marked frames two at a time.
+// FIXUP: `p.out` is a SONO_OUT_FEATURES output of a float32 kernel; only the records it marked (reserved[0] != 0) are
+// recomputed: the wavefronts take the list of marked frames (or, past its capacity, blocks of 64 records) as many frames
+// at a time as they transform (two at 512 / 1024 points, one at 2048 / 4096).
 template <int N, typename In, bool FIXUP>
 __global__ __launch_bounds__(Geo<N>::kWaves * 64) void stft_exact_kernel(StftParams p) {
   using X = Geo<N>;
   constexpr int G = X::G, R = X::R, kWaves = X::kWaves;
-  static_assert(!FIXUP || N == 1024, "the fix-up pass is the 1024-point flavour");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   double2* tw_lds = reinterpret_cast<double2*>(smem);                    // [R-1][G]: row t-1+j of stage T = G t
   float* win_lds = reinterpret_cast<float*>(smem + X::kTwBytes);          // window[j]
@@ -289,9 +289,10 @@ __global__ __launch_bounds__(Geo<N>::kWaves * 64) void stft_exact_kernel(StftPar
     const uint32_t* q = reinterpret_cast<const uint32_t*>(p.tile_scratch);
     const uint32_t listed = q[kQueueCount] < p.fixup ? q[kQueueCount] : p.fixup;   // p.fixup: capacity of the list
     const uint32_t* list = q + kQueueHeader;
-    for (uint64_t e = ((uint64_t)blockIdx.x * kWaves + wave) * 2; e < listed; e += (uint64_t)gridDim.x * kWaves * 2) {
-      const bool two = e + 1 < listed;
-      process(list[e + ((h && two) ? 1 : 0)], h == 0 || two);   // (1024 points: two frames per wavefront)
+    constexpr int kPer = X::kFramesPerWave;  // list entries a wavefront takes at a time (its group h takes entry e + h)
+    for (uint64_t e = ((uint64_t)blockIdx.x * kWaves + wave) * kPer; e < listed; e += (uint64_t)gridDim.x * kWaves * kPer) {
+      const bool mine = e + h < listed;
+      process(list[mine ? e + h : e], mine);
     }
     if (q[kQueueCount] > p.fixup) {
       // more marked records than the list holds: the rest are found by scanning the records themselves, one block of
@@ -308,10 +309,14 @@ __global__ __launch_bounds__(Geo<N>::kWaves * 64) void stft_exact_kernel(StftPar
         while (todo) {  // wave-uniform
           const int i0 = __builtin_ctzll(todo);
           todo &= todo - 1;
-          const bool two = todo != 0;
-          const int i1 = two ? __builtin_ctzll(todo) : i0;
-          if (two) todo &= todo - 1;
-          process(blk * 64 + (h ? i1 : i0), h == 0 || two);
+          if constexpr (X::kFramesPerWave == 2) {
+            const bool two = todo != 0;
+            const int i1 = two ? __builtin_ctzll(todo) : i0;
+            if (two) todo &= todo - 1;
+            process(blk * 64 + (h ? i1 : i0), h == 0 || two);
+          } else {
+            process(blk * 64 + i0, true);
+          }
         }
       }
     }
@@ -367,18 +372,36 @@ int launch_stft_exact(const StftParams& p, void* stream_v) {
 
 // p.tile_scratch: the queue (kQueueHeader words + p.fixup list entries, p.fixup >= 1).
 bool features_fixup_available(const StftParams& p) {
-  return p.n == 1024 && p.twiddles && !p.fb_bin && p.out_kind == SONO_OUT_FEATURES && p.nframes > 0 && p.tile_scratch &&
+  return (p.n == 512 || p.n == 1024 || p.n == 2048 || p.n == 4096) && p.twiddles && !p.fb_bin && p.out_kind == SONO_OUT_FEATURES && p.nframes > 0 && p.tile_scratch &&
          p.fixup > 0 && p.nframes < ((uint64_t)1 << 32);   // frame numbers are 32-bit list entries
 }
 
 uint64_t features_fixup_queue_bytes(uint32_t capacity) { return ((uint64_t)exactreg::kQueueHeader + capacity) * 4; }
 
+namespace exactreg {
+template <int N>
+static int launch_fixup_n(const StftParams& p, hipStream_t stream) {
+  using X = Geo<N>;
+  // the list's length is only known on the device: a full grid, whose wavefronts find their entries or none
+  const uint64_t need = (p.nframes + X::kFramesPerWg - 1) / X::kFramesPerWg;
+  const uint64_t cap = (uint64_t)device_cu_count() * (N == 512 ? 2 : 1);
+  const uint32_t grid = (uint32_t)(need < cap ? need : cap);
+  if (p.in_kind == SONO_IN_I16) {
+    auto kern = stft_exact_kernel<N, int16_t, true>;
+    SONO_GRANT_LDS(kern, X::kLdsBytes);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(X::kWaves * 64), X::kLdsBytes, stream, p);
+  } else {
+    auto kern = stft_exact_kernel<N, float, true>;
+    SONO_GRANT_LDS(kern, X::kLdsBytes);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(X::kWaves * 64), X::kLdsBytes, stream, p);
+  }
+  return hipGetLastError() == hipSuccess ? SONO_OK : SONO_ERR_DEVICE;
+}
+}  // namespace exactreg
+
 // `listed`: the float32 kernel has put the frames it marked into the queue itself (StftParams::feat_queue).
 int launch_features_fixup(const StftParams& p, void* stream_v, bool listed) {
   using namespace exactreg;
-  using X = Geo<1024>;
-  constexpr int kWaves = X::kWaves;
-  constexpr int kLdsBytes = X::kLdsBytes;
   if (!features_fixup_available(p)) return 1;
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_v);
   if (!listed) {
@@ -388,20 +411,12 @@ int launch_features_fixup(const StftParams& p, void* stream_v, bool listed) {
                        reinterpret_cast<const sono_frame_feature*>(p.out) + p.col0, p.nframes,
                        reinterpret_cast<uint32_t*>(p.tile_scratch), p.fixup);
   }
-  // the list's length is only known on the device: a full grid, whose wavefronts find their entries or none
-  const uint64_t need = (p.nframes + kWaves * 2 - 1) / (kWaves * 2);
-  const uint64_t cap = (uint64_t)device_cu_count();   // 192 registers: one workgroup (two wavefronts per SIMD) per CU
-  const uint32_t grid = (uint32_t)(need < cap ? need : cap);
-#define SONO_LAUNCH_F(In)                                                                                        \
-  do {                                                                                                           \
-    auto kern = stft_exact_kernel<1024, In, true>;                                                                 \
-    SONO_GRANT_LDS(kern, kLdsBytes);                                                                             \
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(kWaves * 64), kLdsBytes, stream, p);                               \
-  } while (0)
-  if (p.in_kind == SONO_IN_I16) SONO_LAUNCH_F(int16_t); else SONO_LAUNCH_F(float);
-#undef SONO_LAUNCH_F
-  note_kernel("stft1024_exact_kernel<fixup>");
-  return hipGetLastError() == hipSuccess ? SONO_OK : SONO_ERR_DEVICE;
+  switch (p.n) {
+    case 512: note_kernel("stft512_exact_kernel<fixup>"); return launch_fixup_n<512>(p, stream);
+    case 1024: note_kernel("stft1024_exact_kernel<fixup>"); return launch_fixup_n<1024>(p, stream);
+    case 2048: note_kernel("stft2048_exact_kernel<fixup>"); return launch_fixup_n<2048>(p, stream);
+    default: note_kernel("stft4096_exact_kernel<fixup>"); return launch_fixup_n<4096>(p, stream);
+  }
 }
 
 }  // namespace sono
