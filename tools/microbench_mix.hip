@@ -1,0 +1,96 @@
+// Memory-only model of the 1024-point image writer: 256 persistent workgroups of 16 wavefronts; per round of RF frames
+// a workgroup reads its RF * 256 new float32 samples (linear) and writes RF * 4 bytes (whole 64-byte sectors) of each of
+// the image's 512 rows, 16 bytes per lane.  Nothing is computed.  Variants: which rows a wavefront writes, how the
+// rounds are dealt to the workgroups, reads on / off.  Prints ms and TB/s per variant: the floor the memory system sets
+// for the kernel's access pattern.
+// Build: hipcc -O3 --offload-arch=gfx950 tools/microbench_mix.hip -o scratch/microbench_mix
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+
+#define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
+
+// rows_mode 0: wavefront w writes rows 2w + 32j (two rows per instruction, strided); 1: rows 32w .. 32w+31 (contiguous block)
+// deal 0: contiguous range of rounds per workgroup; 1: round-robin over the grid; 2: round-robin inside an XCD (blocks with
+// equal blockIdx % 8), each XCD a contiguous eighth of the image
+template <int RF>
+__global__ __launch_bounds__(1024) void mix_kernel(const float* __restrict__ pcm, uint8_t* __restrict__ out, float* sink, uint64_t width_px,
+                                                   uint64_t nrounds, int rows_mode, int deal, int reads, int writes) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint64_t pitch = width_px * 4;
+  constexpr int RUN = RF * 4;                 // bytes per row and round
+  constexpr int kLanesPerRow = RUN / 16;      // 32 at RF = 128
+  constexpr int kRowsPerInst = 64 / kLanesPerRow;
+  const uint64_t per_wg = (nrounds + gridDim.x - 1) / gridDim.x;
+  const uint32_t per = gridDim.x >> 3;
+  const uint32_t vb = (blockIdx.x & 7) * per + (blockIdx.x >> 3);  // blocks of one XCD side by side
+  float acc = 0.0f;
+  uint4 v = make_uint4(lane, wave, blockIdx.x, 7);
+  for (uint64_t r = 0; r < per_wg; ++r) {
+    uint64_t round;
+    if (deal == 0) round = (uint64_t)vb * per_wg + r;
+    else if (deal == 1) round = r * gridDim.x + blockIdx.x;
+    else round = (uint64_t)(blockIdx.x & 7) * per * per_wg + r * per + (blockIdx.x >> 3);
+    if (round >= nrounds) continue;
+    if (reads) {  // RF * 256 samples: 16 wavefronts x 64 lanes x 16 bytes = 16 KiB per pass
+      const float4* src = reinterpret_cast<const float4*>(pcm + round * RF * 256);
+      for (int i = threadIdx.x; i < RF * 64; i += 1024) {
+        const float4 t = src[i];
+        acc += t.x + t.y + t.z + t.w;
+      }
+    }
+    if (writes) {
+      const uint64_t col_byte = round * RUN;
+      for (int j = 0; j < 512 / (16 * kRowsPerInst); ++j) {
+        const int row = (rows_mode == 0 ? kRowsPerInst * wave + 16 * kRowsPerInst * j : 32 * wave + kRowsPerInst * j) + lane / kLanesPerRow;
+        uint64_t addr = (uint64_t)row * pitch + col_byte;
+        addr &= ~(uint64_t)63;
+        *reinterpret_cast<uint4*>(out + addr + (lane % kLanesPerRow) * 16) = v;
+      }
+    }
+  }
+  if (acc == 12345.678f) sink[0] = acc;
+}
+
+int main(int argc, char** argv) {
+  const uint64_t width = 5399996ull;  // 1 h at 384 kHz, hop 256
+  const uint64_t img = width * 4 * 512, nsamp = width * 256 + 1024;
+  uint8_t* out = nullptr;
+  float *pcm = nullptr, *sink = nullptr;
+  CHECK(hipMalloc(&out, img + 4096));
+  CHECK(hipMalloc(&pcm, nsamp * 4 + 65536));
+  CHECK(hipMalloc(&sink, 64));
+  CHECK(hipMemset(out, 0, img + 4096));
+  CHECK(hipMemset(pcm, 0, nsamp * 4 + 65536));
+  hipEvent_t e0, e1;
+  CHECK(hipEventCreate(&e0));
+  CHECK(hipEventCreate(&e1));
+  printf("{\"image_gb\": %.3f, \"pcm_gb\": %.3f}\n", img / 1e9, nsamp * 4 / 1e9);
+  for (int rf : {128, 256})
+    for (int rw = 0; rw < 3; ++rw)             // 0: writes only, 1: reads only, 2: both
+      for (int rows_mode = 0; rows_mode < 2; ++rows_mode)
+        for (int deal = 0; deal < 3; ++deal) {
+          if (rw == 1 && (rows_mode != 0)) continue;
+          const uint64_t nrounds = (width + rf - 1) / rf;
+          const int reads = rw != 0, writes = rw != 1;
+          float best = 1e30f;
+          for (int rep = 0; rep < 4; ++rep) {
+            CHECK(hipEventRecord(e0));
+            if (rf == 128) hipLaunchKernelGGL(mix_kernel<128>, dim3(256), dim3(1024), 0, 0, pcm, out, sink, width, nrounds, rows_mode, deal, reads, writes);
+            else hipLaunchKernelGGL(mix_kernel<256>, dim3(256), dim3(1024), 0, 0, pcm, out, sink, width, nrounds, rows_mode, deal, reads, writes);
+            CHECK(hipEventRecord(e1));
+            CHECK(hipEventSynchronize(e1));
+            float ms = 0;
+            CHECK(hipEventElapsedTime(&ms, e0, e1));
+            if (rep > 0 && ms < best) best = ms;
+          }
+          const double bytes = (writes ? (double)img : 0.0) + (reads ? (double)nsamp * 4 : 0.0);
+          printf("{\"round_frames\": %d, \"traffic\": \"%s\", \"rows\": \"%s\", \"deal\": \"%s\", \"ms\": %.3f, \"tb_per_s\": %.3f}\n", rf,
+                 rw == 0 ? "writes" : rw == 1 ? "reads" : "reads+writes", rows_mode ? "block of 32 per wavefront" : "strided",
+                 deal == 0 ? "contiguous range" : deal == 1 ? "round-robin over the grid" : "round-robin inside an XCD", best,
+                 bytes / (best * 1e-3) / 1e12);
+          fflush(stdout);
+        }
+  return 0;
+}
