@@ -400,7 +400,7 @@ __global__ __launch_bounds__(kWaves * 64) void stft2048_kernel(StftParams p, Fas
 #pragma unroll
           for (int a = 32; a < 32 + HOP64; ++a) raw[a] = ld<In>(x0, 64 * a);
         }
-        if constexpr (TABLE) loudest = max_abs(raw);
+        if constexpr (TABLE) loudest = max_abs_plain(raw);
 #pragma unroll
         for (int a = 0; a < 32; ++a) {
           const float w = win_lds[64 * a + lane];
@@ -663,7 +663,7 @@ __global__ __launch_bounds__(kWaves * 64) void stft2048_rgba_kernel(StftParams p
     if (f0 < p.nframes) {  // wave-uniform
       if constexpr (TABLE) {
         // (a NaN sample does not compare as loud and needs no second look: it poisons every bin either way)
-        if (mode == 0 && p.loud_thr_raw > 0.0f && __builtin_amdgcn_ballot_w64(max_abs(raw) > p.loud_thr_raw) != 0) mode = 1;
+        if (mode == 0 && p.loud_thr_raw > 0.0f && __builtin_amdgcn_ballot_w64(max_abs_plain(raw) > p.loud_thr_raw) != 0) mode = 1;
       }
       float re[32], im[32];
 #pragma unroll

@@ -260,12 +260,13 @@ __global__ __launch_bounds__(kWaves * 64) void stft4096_kernel(StftParams p, Fas
     if (active) {
       if (mode == 0 && p.loud_thr_raw > 0.0f && p.redo_scratch) {
         // (a NaN sample does not compare as loud and needs no second look: it poisons every bin either way)
-        float m = 0.0f;
+        float m0 = 0.0f, m1 = 0.0f;
 #pragma unroll
-        for (int a = 0; a < 16; ++a)
-          m = __builtin_fmaxf(m, __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(raw[a].x), __builtin_fabsf(raw[a].y)),
-                                                 __builtin_fmaxf(__builtin_fabsf(raw[a].z), __builtin_fabsf(raw[a].w))));
-        if (__builtin_amdgcn_ballot_w64(m > p.loud_thr_raw) != 0) mode = 1;
+        for (int a = 0; a < 16; ++a) {
+          m0 = max3_abs(raw[a].x, raw[a].y, m0);
+          m1 = max3_abs(raw[a].z, raw[a].w, m1);
+        }
+        if (__builtin_amdgcn_ballot_w64(__builtin_fmaxf(m0, m1) > p.loud_thr_raw) != 0) mode = 1;
       }
       float re[32], im[32];
       {

@@ -342,8 +342,7 @@ __global__ __launch_bounds__(kWaves * 64) void stft512_kernel(StftParams p, Fast
         for (int a = 0; a < 16; ++a) {
           const float v0 = ld<In>(x0, 32 * a), v1 = ld<In>(x1, 32 * a), v2 = ld<In>(x2, 32 * a), v3 = v3s[a];
           if constexpr (TABLE)
-            loudest = __builtin_fmaxf(loudest, __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(v0), __builtin_fabsf(v1)),
-                                                               __builtin_fmaxf(__builtin_fabsf(v2), __builtin_fabsf(v3))));
+            loudest = max3_abs(v2, v3, max3_abs(v0, v1, loudest));
           re[brev4(a)] = v0 * win[a];
           im[brev4(a)] = v1 * win[a];
           re[16 + brev4(a)] = v2 * win[a];
