@@ -13,10 +13,12 @@
 
 // rows_mode 0: wavefront w writes rows 2w + 32j (two rows per instruction, strided); 1: rows 32w .. 32w+31 (contiguous block)
 // deal 0: contiguous range of rounds per workgroup; 1: round-robin over the grid; 2: round-robin inside an XCD (blocks with
-// equal blockIdx % 8), each XCD a contiguous eighth of the image
+// equal blockIdx % 8), each XCD a contiguous eighth of the image; 3: as 2, in chunks of four consecutive rounds per workgroup
+// align 1: every row run starts on a 64-byte boundary; 0: runs start where the round starts in that row (rows are 48 bytes
+// mod 64 apart, so three rows in four share their first and last sector with the neighbouring round)
 template <int RF>
 __global__ __launch_bounds__(1024) void mix_kernel(const float* __restrict__ pcm, uint8_t* __restrict__ out, float* sink, uint64_t width_px,
-                                                   uint64_t nrounds, int rows_mode, int deal, int reads, int writes) {
+                                                   uint64_t nrounds, int rows_mode, int deal, int reads, int writes, int align) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint64_t pitch = width_px * 4;
   constexpr int RUN = RF * 4;                 // bytes per row and round
@@ -31,7 +33,8 @@ __global__ __launch_bounds__(1024) void mix_kernel(const float* __restrict__ pcm
     uint64_t round;
     if (deal == 0) round = (uint64_t)vb * per_wg + r;
     else if (deal == 1) round = r * gridDim.x + blockIdx.x;
-    else round = (uint64_t)(blockIdx.x & 7) * per * per_wg + r * per + (blockIdx.x >> 3);
+    else if (deal == 2) round = (uint64_t)(blockIdx.x & 7) * per * per_wg + r * per + (blockIdx.x >> 3);
+    else round = (uint64_t)(blockIdx.x & 7) * per * per_wg + ((r >> 2) * per + (blockIdx.x >> 3)) * 4 + (r & 3);
     if (round >= nrounds) continue;
     if (reads) {  // RF * 256 samples: 16 wavefronts x 64 lanes x 16 bytes = 16 KiB per pass
       const float4* src = reinterpret_cast<const float4*>(pcm + round * RF * 256);
@@ -45,7 +48,7 @@ __global__ __launch_bounds__(1024) void mix_kernel(const float* __restrict__ pcm
       for (int j = 0; j < 512 / (16 * kRowsPerInst); ++j) {
         const int row = (rows_mode == 0 ? kRowsPerInst * wave + 16 * kRowsPerInst * j : 32 * wave + kRowsPerInst * j) + lane / kLanesPerRow;
         uint64_t addr = (uint64_t)row * pitch + col_byte;
-        addr &= ~(uint64_t)63;
+        if (align) addr &= ~(uint64_t)63;
         *reinterpret_cast<uint4*>(out + addr + (lane % kLanesPerRow) * 16) = v;
       }
     }
@@ -70,15 +73,17 @@ int main(int argc, char** argv) {
   for (int rf : {128, 256})
     for (int rw = 0; rw < 3; ++rw)             // 0: writes only, 1: reads only, 2: both
       for (int rows_mode = 0; rows_mode < 2; ++rows_mode)
-        for (int deal = 0; deal < 3; ++deal) {
-          if (rw == 1 && (rows_mode != 0)) continue;
+        for (int deal = 0; deal < 4; ++deal)
+         for (int align = 1; align >= 0; --align) {
+          if (rw == 1 && (rows_mode != 0 || align == 0)) continue;
+          if (rw != 1 && rows_mode != 0 && align == 0) continue;
           const uint64_t nrounds = (width + rf - 1) / rf;
           const int reads = rw != 0, writes = rw != 1;
           float best = 1e30f;
           for (int rep = 0; rep < 4; ++rep) {
             CHECK(hipEventRecord(e0));
-            if (rf == 128) hipLaunchKernelGGL(mix_kernel<128>, dim3(256), dim3(1024), 0, 0, pcm, out, sink, width, nrounds, rows_mode, deal, reads, writes);
-            else hipLaunchKernelGGL(mix_kernel<256>, dim3(256), dim3(1024), 0, 0, pcm, out, sink, width, nrounds, rows_mode, deal, reads, writes);
+            if (rf == 128) hipLaunchKernelGGL(mix_kernel<128>, dim3(256), dim3(1024), 0, 0, pcm, out, sink, width, nrounds, rows_mode, deal, reads, writes, align);
+            else hipLaunchKernelGGL(mix_kernel<256>, dim3(256), dim3(1024), 0, 0, pcm, out, sink, width, nrounds, rows_mode, deal, reads, writes, align);
             CHECK(hipEventRecord(e1));
             CHECK(hipEventSynchronize(e1));
             float ms = 0;
@@ -86,9 +91,10 @@ int main(int argc, char** argv) {
             if (rep > 0 && ms < best) best = ms;
           }
           const double bytes = (writes ? (double)img : 0.0) + (reads ? (double)nsamp * 4 : 0.0);
-          printf("{\"round_frames\": %d, \"traffic\": \"%s\", \"rows\": \"%s\", \"deal\": \"%s\", \"ms\": %.3f, \"tb_per_s\": %.3f}\n", rf,
+          printf("{\"round_frames\": %d, \"traffic\": \"%s\", \"rows\": \"%s\", \"deal\": \"%s\", \"runs\": \"%s\", \"ms\": %.3f, \"tb_per_s\": %.3f}\n", rf,
                  rw == 0 ? "writes" : rw == 1 ? "reads" : "reads+writes", rows_mode ? "block of 32 per wavefront" : "strided",
-                 deal == 0 ? "contiguous range" : deal == 1 ? "round-robin over the grid" : "round-robin inside an XCD", best,
+                 deal == 0 ? "contiguous range" : deal == 1 ? "round-robin over the grid" : deal == 2 ? "round-robin inside an XCD" : "chunks of 4 round-robin inside an XCD",
+                 align ? "whole sectors" : "unaligned", best,
                  bytes / (best * 1e-3) / 1e12);
           fflush(stdout);
         }
