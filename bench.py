@@ -24,6 +24,7 @@ sample of the same signal.
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 import zlib
@@ -338,6 +339,25 @@ def main():
         # the kernel's algorithmic rate against what this box's memory system does for a linear read + write mix
         result["roofline"]["frac_of_measured_copy"] = round(result["roofline"]["achieved"] / result["roofline"]["measured_copy_gbps"], 4)
 
+    if rank == 0 and world == 1 and args.out == "rgba":
+        # The floor the memory system sets for this kernel's access pattern, measured now: tools/microbench_mix is the
+        # kernel with every instruction but its loads and stores removed (same grid, same rounds of 128 frames, the
+        # same whole-sector row runs of the same image, the same linear sample reads), as a child process of its own.
+        exe = os.path.join(ROOT, "tools", "microbench_mix")
+        entry = None
+        if os.path.exists(exe):
+            try:
+                r = subprocess.run([exe, "floor", str(int(geo.frames))], capture_output=True, text=True, timeout=120)
+                m = json.loads(r.stdout.strip().splitlines()[-1]) if r.returncode == 0 and r.stdout.strip() else None
+            except (subprocess.TimeoutExpired, ValueError):
+                m = None
+            if m:
+                entry = {"ms": round(m["both_ms"], 4), "writes_alone_ms": round(m["writes_ms"], 4), "reads_alone_ms": round(m["reads_ms"], 4),
+                         "frac_of_peak": round((m["image_bytes"] + m["sample_bytes"]) / (m["both_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                         "kernel_over_model": round(kern_ms / m["both_ms"], 4),
+                         "what": "tools/microbench_mix.hip: the kernel's loads and stores with no arithmetic"}
+        result["roofline"]["memory_only_model"] = entry
+
     if rank == 0 and world == 1:
         # The vector-ALU roofline beside the HBM one: at hop = N/4 the transform is ~200 flop per sample over 6-12
         # bytes, i.e. at or above the machine balance, so instruction issue -- not bytes -- fills most of the time.
@@ -401,7 +421,6 @@ def main():
         del x16
         # the headline workload through the JavaScript host (N-API addon): must agree with the figure above
         import shutil
-        import subprocess
         node = shutil.which("node")
         if node and os.path.isfile(os.path.join(ROOT, "node", "build", "sonospec.node")):
             try:
@@ -417,7 +436,6 @@ def main():
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         import shutil
-        import subprocess
         import tempfile
         import oracle
         # Every core this process may run on -- unless the box states its CPU share for one GPU's job in OMP_NUM_THREADS

@@ -3,11 +3,13 @@
 // the image's 512 rows, 16 bytes per lane.  Nothing is computed.  Variants: which rows a wavefront writes, how the
 // rounds are dealt to the workgroups, reads on / off.  Prints ms and TB/s per variant: the floor the memory system sets
 // for the kernel's access pattern.
-// Build: hipcc -O3 --offload-arch=gfx950 tools/microbench_mix.hip -o scratch/microbench_mix
+// `microbench_mix floor [frames]` prints one line with the kernel's own pattern only (bench.py puts it beside the roofline).
+// Built by spectrogram_amd/csrc/Makefile into tools/microbench_mix.
 #include <hip/hip_runtime.h>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <string>
 
 #define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
 
@@ -57,7 +59,8 @@ __global__ __launch_bounds__(1024) void mix_kernel(const float* __restrict__ pcm
 }
 
 int main(int argc, char** argv) {
-  const uint64_t width = 5399996ull;  // 1 h at 384 kHz, hop 256
+  const uint64_t width = argc > 2 ? strtoull(argv[2], nullptr, 10) : 5399996ull;  // frames; default 1 h at 384 kHz, hop 256
+  if (width < 128 || width > (1ull << 26)) { fprintf(stderr, "frames out of range\n"); return 1; }
   const uint64_t img = width * 4 * 512, nsamp = width * 256 + 1024;
   uint8_t* out = nullptr;
   float *pcm = nullptr, *sink = nullptr;
@@ -69,6 +72,28 @@ int main(int argc, char** argv) {
   hipEvent_t e0, e1;
   CHECK(hipEventCreate(&e0));
   CHECK(hipEventCreate(&e1));
+  if (argc > 1 && std::string(argv[1]) == "floor") {
+    // one line for bench.py: the pattern the image writer uses (rounds of 128 frames, whole sectors, a contiguous range of
+    // rounds per workgroup), writes alone, reads alone, both
+    const uint64_t nrounds = (width + 127) / 128;
+    float ms3[3];
+    for (int rw = 0; rw < 3; ++rw) {
+      float best = 1e30f;
+      for (int rep = 0; rep < 4; ++rep) {
+        CHECK(hipEventRecord(e0));
+        hipLaunchKernelGGL(mix_kernel<128>, dim3(256), dim3(1024), 0, 0, pcm, out, sink, width, nrounds, 0, 0, rw != 0, rw != 1, 1);
+        CHECK(hipEventRecord(e1));
+        CHECK(hipEventSynchronize(e1));
+        float ms = 0;
+        CHECK(hipEventElapsedTime(&ms, e0, e1));
+        if (rep > 0 && ms < best) best = ms;
+      }
+      ms3[rw] = best;
+    }
+    printf("{\"frames\": %llu, \"image_bytes\": %llu, \"sample_bytes\": %llu, \"writes_ms\": %.4f, \"reads_ms\": %.4f, \"both_ms\": %.4f}\n",
+           (unsigned long long)width, (unsigned long long)img, (unsigned long long)(nsamp * 4), ms3[0], ms3[1], ms3[2]);
+    return 0;
+  }
   printf("{\"image_gb\": %.3f, \"pcm_gb\": %.3f}\n", img / 1e9, nsamp * 4 / 1e9);
   for (int rf : {128, 256})
     for (int rw = 0; rw < 3; ++rw)             // 0: writes only, 1: reads only, 2: both
