@@ -91,11 +91,15 @@ typedef enum sono_arith {
                               transform the loud frames once more, one frame per transform, inside the same
                               launch (sono_kernel_route names such a kernel <...,redo>), so the 1 LSB holds
                               for every input.
-                              Samples are taken to be finite, as decoded PCM is: the float32 kernels transform
-                              two frames at a time, so a NaN or an infinite sample also takes the frame that
+                              Samples are taken to be finite and within full scale (|x| <= 1), as decoded PCM
+                              is.  Float32 resolves about 2e-7 of a transform's largest value: a frame whose
+                              samples are far beyond full scale buries its own bins near the display floor,
+                              and those of the frame it shares a transform with, under that rounding (measured:
+                              the 1 LSB still holds at 10 times full scale; a tone at 30 times full scale
+                              over a floor near -90 dB moves a few plugin indices by 2).  Likewise a NaN or an infinite sample also takes the frame that
                               shares a transform with its own (the reference loses only the frames that contain
-                              the sample); SONO_ARITH_EXACT_F64 transforms every frame alone and reproduces the
-                              reference for such input too.
+                              the sample).  SONO_ARITH_EXACT_F64 transforms every frame alone in the
+                              reference's own arithmetic and reproduces it for such input too.
                               SONO_OUT_F32_DB: within 0.01 dB of the reference's own arithmetic for every
                               bin above that floor that lies within 80 dB of its frame's largest bin, and
                               within 0.04 dB for the bins 80..95 dB below it (measured worst case 0.026 dB

@@ -288,6 +288,40 @@ def test_colour_indices_within_one_lsb_under_near_full_scale_tones(n):
                      4096: "stft4096_kernel<redo>"}[n], route
 
 
+@pytest.mark.parametrize("n", [512, 1024, 2048, 4096])
+def test_one_lsb_holds_with_margin_beyond_full_scale(n):
+    """The float32 kernels state their 1-LSB promise for samples within full scale (|x| <= 1): float32 resolves about
+    2e-7 of a transform's largest value, and the display floor sits 100 dB below a full-scale tone.  A float recording
+    that was normalised carelessly must not fall off that edge at once: a long tone at 8 times full scale over a quiet
+    floor (worst case: the tone's own frames, whose far bins are the floor) and bursts at 8 times full scale next to quiet
+    frames (worst case: the frame that shares a transform with a burst) stay within 1 LSB on both paths."""
+    hop = n // 4
+    rng = np.random.default_rng(n + 8)
+    L = n + hop * 300
+    t = np.arange(L, dtype=np.float64)
+    for quiet, shape in ((1e-3, "tone"), (1e-3, "bursts"), (0.2, "tone"), (0.2, "bursts")):
+        x = rng.standard_normal(L) * quiet
+        if shape == "tone":
+            seg = slice(20 * hop, 20 * hop + 40 * n)
+            x[seg] += 8.0 * np.sin(2 * np.pi * 0.125 * t[seg])
+        else:
+            for s in range(5 * hop, L - 2 * n, 37 * hop):
+                x[s:s + n // 2] += 8.0 * np.sin(0.7 * t[:n // 2])
+        x = x.astype(np.float32)
+        _, ref = oracle.worker_render(x, n, 75.0, None, want_index=True)
+        with E.Engine(fft_n=n, hop=hop, window_id=F.WIN_WORKER_HANN, scale_mode=F.SCALE_WORKER_LOG5,
+                      frame_rule=F.FRAMES_WORKER_COMPAT, twiddle_mode=F.TW_ACCURATE, arith=F.ARITH_FAST_F32,
+                      out_kind=F.OUT_U8_INDEX) as eng:
+            got = eng.stft(x)
+        m = min(len(got), len(ref))
+        d = np.abs(got[:m].astype(np.int16) - ref[:m].astype(np.int16))
+        assert d.max() <= 1 and (d != 0).mean() < 0.02, (n, quiet, shape, "worker", int((d > 1).sum()))
+        refp = oracle.plugin_get_frequencies(x, n, n - hop)
+        with plugin_engine(n, hop, F.ARITH_FAST_F32) as eng:
+            d = cyc_diff(eng.stft(x), refp)
+        assert d.max() <= 1 and (d != 0).mean() < 0.02, (n, quiet, shape, "plugin", int((d > 1).sum()))
+
+
 def test_plugin_accurate_twiddles_differ_from_recurrence_at_4096():
     """The recurrence twiddles are part of the reference's result: at 4096 points they sit up to 3e-5
     away from the true roots of unity, which moves visible bins by more than the 0.01 dB tolerance, so
