@@ -13,20 +13,25 @@ namespace sono {
 namespace rgba_flush {
 
 constexpr int kRoundFrames = 256;                  // frames per workgroup round (largest)
-// slot: [reader wavefront 16][frame group 64][bin quad 8] x 16 bytes (four frames x four bins), 128 KiB; a
-// workgroup owns two of them
+// slot: [reader unit of 32 bins][quarter of 8 bins][frame group RF/4][bin quad 2] x 16 bytes (four frames x four bins):
+// what one wavefront reads for one quarter is one contiguous run (64 lanes x 16 bytes per 128 frames), so every cache
+// line of the slot is fetched once -- with the bin quads of a unit side by side instead, a line served four quarters in
+// four different iterations and came back from memory for each (2.1 x the slot's bytes in reads).  A workgroup owns two
+// slots
 constexpr int kRoundBytes = 128 * kRoundFrames * 4;
 constexpr int kLutBytes = 1024;
 typedef uint32_t u32x4_unaligned __attribute__((ext_vector_type(4), aligned(4)));
 
 // cell of the bin quad kq (bins 4kq .. 4kq+3) of frame group fg (frames 4fg .. 4fg+3 of the round), in uint4 units
 template <int RF = 256>
-__device__ __forceinline__ int slot_cell(int kq, int fg) { return ((kq >> 3) * (RF / 4) + fg) * 8 + (kq & 7); }
+__device__ __forceinline__ int slot_cell(int kq, int fg) {
+  return (((kq >> 3) * 4 + ((kq & 7) >> 1)) * (RF / 4) + fg) * 2 + (kq & 1);
+}
 
 // Writes one quarter (`part` = 0..3) of a workgroup round (RF frames starting at frame `frame0`,
 // indices in `slot`) to the RGBA image.  Wavefront w owns the 32 bins 32w .. 32w+31 (32 image rows) and
 // writes the eight rows of bins 32w + 8*part .. +7 per quarter, complete: per step u lane j reads the
-// bin quad 2*part + (j & 1) of the frame group 32u + (j >> 1), i.e. 4 bins x 4 frames, and stores four
+// bin quad 2*part + (j & 1) of the frame group 32u + (j >> 1), i.e. 4 bins x 4 frames (cell `lane` of the quarter's run), and stores four
 // 16-byte pixel runs; 32 lanes form a 512-byte run of one row and the RF/128 steps complete its run of 4*RF bytes,
 // so that sectors are whole when they leave L2 (up to the ends of the run, which the neighbouring
 // workgroup completes).  Addresses are a wave-uniform base plus a 32-bit lane offset.
@@ -35,10 +40,9 @@ template <int RF = 256>
 __device__ __forceinline__ void flush_quarter_load(uint4 (&q)[2], const uint32_t* __restrict__ slot, int part, int wave, int lane) {
   asm volatile("" : "+s"(wave));
   asm volatile("" : "+v"(lane));
-  const int qsel = lane & 1, fsel = lane >> 1;
-  const uint4* sp = reinterpret_cast<const uint4*>(slot) + wave * ((RF / 4) * 8) + fsel * 8 + 2 * part + qsel;
+  const uint4* sp = reinterpret_cast<const uint4*>(slot) + (wave * 4 + part) * ((RF / 4) * 2) + lane;
 #pragma unroll
-  for (int u = 0; u < RF / 128; ++u) q[u] = sp[u * 32 * 8];
+  for (int u = 0; u < RF / 128; ++u) q[u] = sp[u * 64];
 }
 // second half: colours and stores
 template <int RF = 256>
