@@ -20,7 +20,8 @@
 // mod 64 apart, so three rows in four share their first and last sector with the neighbouring round)
 template <int RF>
 __global__ __launch_bounds__(1024) void mix_kernel(const float* __restrict__ pcm, uint8_t* __restrict__ out, float* sink, uint64_t width_px,
-                                                   uint64_t nrounds, int rows_mode, int deal, int reads, int writes, int align) {
+                                                   uint64_t nrounds, int rows_mode, int deal, int reads, int writes, int align,
+                                                   int rows = 512, int hop = 256, uint4* slots = nullptr) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint64_t pitch = width_px * 4;
   constexpr int RUN = RF * 4;                 // bytes per row and round
@@ -39,15 +40,25 @@ __global__ __launch_bounds__(1024) void mix_kernel(const float* __restrict__ pcm
     else round = (uint64_t)(blockIdx.x & 7) * per * per_wg + ((r >> 2) * per + (blockIdx.x >> 3)) * 4 + (r & 3);
     if (round >= nrounds) continue;
     if (reads) {  // RF * 256 samples: 16 wavefronts x 64 lanes x 16 bytes = 16 KiB per pass
-      const float4* src = reinterpret_cast<const float4*>(pcm + round * RF * 256);
-      for (int i = threadIdx.x; i < RF * 64; i += 1024) {
+      const float4* src = reinterpret_cast<const float4*>(pcm + round * RF * hop);
+      for (int i = threadIdx.x; i < RF * hop / 4; i += 1024) {
         const float4 t = src[i];
         acc += t.x + t.y + t.z + t.w;
       }
     }
     if (writes) {
       const uint64_t col_byte = round * RUN;
-      for (int j = 0; j < 512 / (16 * kRowsPerInst); ++j) {
+      if (slots) {  // the round's colour indices (rows x RF bytes) parked in this workgroup's slot and read back a round later
+        uint4* slot = slots + (size_t)(2 * blockIdx.x + (r & 1)) * (rows * RF / 16);
+        uint4* prev = slots + (size_t)(2 * blockIdx.x + ((r + 1) & 1)) * (rows * RF / 16);
+        uint4 t = v;
+        for (int i = threadIdx.x; i < rows * RF / 16; i += 1024) {
+          if (r > 0) { const uint4 u = prev[i]; t.x ^= u.x; t.y += u.w; }
+          slot[i] = v;
+        }
+        v.z = t.x + t.y;
+      }
+      for (int j = 0; j < rows / (16 * kRowsPerInst); ++j) {
         const int row = (rows_mode == 0 ? kRowsPerInst * wave + 16 * kRowsPerInst * j : 32 * wave + kRowsPerInst * j) + lane / kLanesPerRow;
         uint64_t addr = (uint64_t)row * pitch + col_byte;
         if (align) addr &= ~(uint64_t)63;
@@ -61,7 +72,13 @@ __global__ __launch_bounds__(1024) void mix_kernel(const float* __restrict__ pcm
 int main(int argc, char** argv) {
   const uint64_t width = argc > 2 ? strtoull(argv[2], nullptr, 10) : 5399996ull;  // frames; default 1 h at 384 kHz, hop 256
   if (width < 128 || width > (1ull << 26)) { fprintf(stderr, "frames out of range\n"); return 1; }
-  const uint64_t img = width * 4 * 512, nsamp = width * 256 + 1024;
+  // floor mode, optional: rows of the image (512; 1024 = the 2048-point writer), hop (256; 512), "slot" = the round's colour
+  // indices go through a global scratch slot as in the 2048-point writer
+  const int rows = argc > 3 ? atoi(argv[3]) : 512, hop = argc > 4 ? atoi(argv[4]) : 256;
+  if ((rows != 512 && rows != 1024) || (hop != 256 && hop != 512)) { fprintf(stderr, "rows 512|1024, hop 256|512\n"); return 1; }
+  const uint64_t img = width * 4 * rows, nsamp = width * hop + 4096;
+  void* slots = nullptr;
+  if (argc > 5 && std::string(argv[5]) == "slot") { CHECK(hipMalloc(&slots, (size_t)256 * 2 * rows * 128)); CHECK(hipMemset(slots, 0, (size_t)256 * 2 * rows * 128)); }
   uint8_t* out = nullptr;
   float *pcm = nullptr, *sink = nullptr;
   CHECK(hipMalloc(&out, img + 4096));
@@ -81,7 +98,8 @@ int main(int argc, char** argv) {
       float best = 1e30f;
       for (int rep = 0; rep < 4; ++rep) {
         CHECK(hipEventRecord(e0));
-        hipLaunchKernelGGL(mix_kernel<128>, dim3(256), dim3(1024), 0, 0, pcm, out, sink, width, nrounds, 0, 0, rw != 0, rw != 1, 1);
+        hipLaunchKernelGGL(mix_kernel<128>, dim3(256), dim3(1024), 0, 0, pcm, out, sink, width, nrounds, 0, 0, rw != 0, rw != 1, 1, rows, hop,
+                           (uint4*)(rw == 2 ? slots : nullptr));
         CHECK(hipEventRecord(e1));
         CHECK(hipEventSynchronize(e1));
         float ms = 0;
@@ -90,8 +108,8 @@ int main(int argc, char** argv) {
       }
       ms3[rw] = best;
     }
-    printf("{\"frames\": %llu, \"image_bytes\": %llu, \"sample_bytes\": %llu, \"writes_ms\": %.4f, \"reads_ms\": %.4f, \"both_ms\": %.4f}\n",
-           (unsigned long long)width, (unsigned long long)img, (unsigned long long)(nsamp * 4), ms3[0], ms3[1], ms3[2]);
+    printf("{\"frames\": %llu, \"rows\": %d, \"hop\": %d, \"slot\": %s, \"image_bytes\": %llu, \"sample_bytes\": %llu, \"writes_ms\": %.4f, \"reads_ms\": %.4f, \"both_ms\": %.4f}\n",
+           (unsigned long long)width, rows, hop, slots ? "true" : "false", (unsigned long long)img, (unsigned long long)(nsamp * 4), ms3[0], ms3[1], ms3[2]);
     return 0;
   }
   printf("{\"image_gb\": %.3f, \"pcm_gb\": %.3f}\n", img / 1e9, nsamp * 4 / 1e9);
