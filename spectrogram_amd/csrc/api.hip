@@ -25,6 +25,7 @@ struct sono_ctx {
   hipStream_t own_stream = nullptr;
   hipStream_t stream = nullptr;
   hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+  hipEvent_t ev_switch = nullptr;  // orders a newly set stream behind the work already enqueued on the previous one
   // device tables
   float* d_window = nullptr;
   void* d_tw = nullptr;       // float2[n-1] (fast) or double2[n-1] (exact)
@@ -291,6 +292,7 @@ sono_ctx* sono_create(int device, const sono_config* cfg) {
   c->stream = c->own_stream;
   if ((e = hipEventCreate(&c->ev_start)) != hipSuccess) return bail("hipEventCreate", e);
   if ((e = hipEventCreate(&c->ev_stop)) != hipSuccess) return bail("hipEventCreate", e);
+  if ((e = hipEventCreateWithFlags(&c->ev_switch, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
   if ((e = hipMalloc((void**)&c->d_window, sizeof(float) * n)) != hipSuccess) return bail("hipMalloc(window)", e);
   if ((e = hipMalloc(&c->d_tw, sizeof(double) * 2 * n)) != hipSuccess) return bail("hipMalloc(twiddles)", e);
   // entries [0, 256): the caller's colour map; [256, 512): the grey ramp used when none is set
@@ -335,6 +337,7 @@ void sono_destroy(sono_ctx* c) {
     if (b) (void)hipFree(b);
   if (c->ev_start) (void)hipEventDestroy(c->ev_start);
   if (c->ev_stop) (void)hipEventDestroy(c->ev_stop);
+  if (c->ev_switch) (void)hipEventDestroy(c->ev_switch);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   delete c;
 }
@@ -349,7 +352,15 @@ int sono_get_config(const sono_ctx* c, sono_config* out) {
 
 int sono_set_stream(sono_ctx* c, void* s) {
   if (!c) return SONO_ERR_ARG;
-  c->stream = s ? reinterpret_cast<hipStream_t>(s) : c->own_stream;
+  hipStream_t next = s ? reinterpret_cast<hipStream_t>(s) : c->own_stream;
+  if (next != c->stream) {
+    // the context's scratch (image slots, index chunk, parked half transforms) is shared by all its launches: what
+    // the new stream runs must not overtake what the previous one still has in flight
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipEventRecord(c->ev_switch, c->stream));
+    HIP_TRY(c, hipStreamWaitEvent(next, c->ev_switch, 0));
+    c->stream = next;
+  }
   return SONO_OK;
 }
 

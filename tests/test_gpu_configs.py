@@ -462,3 +462,47 @@ def test_other_sizes_beyond_32_bit_sample_offsets(n, hop):
     assert d.max() <= 1, route
     k = (g.frames - 2) % period_frames
     assert np.array_equal(tail, np.concatenate([head, head])[k:k + 2]), route
+
+
+def test_stream_switch_orders_launches_that_share_the_contexts_scratch():
+    """sono_set_stream while the previous stream still runs the context's kernels: the 2048-point image writer parks
+    every round's colour indices in context-owned scratch, so a launch on the new stream must not overtake the one
+    before it.  The library makes the new stream wait for the old one (an event, no host wait); two recordings
+    enqueued back to back on alternating streams come out as they do one at a time."""
+    torch = pytest.importorskip("torch")
+    n, hop = 2048, 512
+    rng = np.random.default_rng(77)
+    La, Lb = n + hop * 30000, n + hop * 29000 + 13
+    xa = (rng.standard_normal(La) * 0.1).astype(np.float32)
+    xb = (rng.standard_normal(Lb) * 0.3).astype(np.float32)
+    lut = (np.arange(1024, dtype=np.uint32) * 7 % 251).astype(np.uint8)
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    with E.Engine(fft_n=n, hop=hop, window_id=F.WIN_WORKER_HANN, scale_mode=F.SCALE_WORKER_LOG5,
+                  frame_rule=F.FRAMES_WORKER_COMPAT, twiddle_mode=F.TW_ACCURATE, arith=F.ARITH_FAST_F32,
+                  out_kind=F.OUT_RGBA8) as eng:
+        eng.set_colormap(lut)
+        na, nb = eng.out_bytes(La), eng.out_bytes(Lb)
+        da, db, oa, ob = eng.device_malloc(xa.nbytes), eng.device_malloc(xb.nbytes), eng.device_malloc(na), eng.device_malloc(nb)
+        try:
+            eng.copy_to_device(da, xa)
+            eng.copy_to_device(db, xb)
+            eng.stft_device(da, La, oa, na)
+            assert "stft2048_rgba_kernel" in eng.kernel_route()
+            eng.stft_device(db, Lb, ob, nb)
+            want_a, want_b = eng.copy_to_host(np.empty(na, np.uint8), oa), eng.copy_to_host(np.empty(nb, np.uint8), ob)
+            for rep in range(6):
+                eng.copy_to_device(oa, np.zeros(na, np.uint8))
+                eng.copy_to_device(ob, np.zeros(nb, np.uint8))
+                eng.wait()
+                eng.set_stream(s1.cuda_stream)
+                eng.stft_device(da, La, oa, na, wait=False)
+                eng.set_stream(s2.cuda_stream)
+                eng.stft_device(db, Lb, ob, nb, wait=False)
+                eng.wait()                                   # the second stream, which waited for the first
+                got_a, got_b = eng.copy_to_host(np.empty(na, np.uint8), oa), eng.copy_to_host(np.empty(nb, np.uint8), ob)
+                assert np.array_equal(got_a, want_a) and np.array_equal(got_b, want_b), rep
+            eng.set_stream(None)
+        finally:
+            torch.cuda.synchronize()
+            for p in (da, db, oa, ob):
+                eng.device_free(p)
