@@ -566,8 +566,7 @@ __global__ __launch_bounds__(kWaves * 64) void stft2048_kernel(StftParams p, Fas
 // frames (wavefront w: frames 32i + 2w, +1 of the round); a slot holds 1024 bins x 128 frames = 128 KiB as 32 reader
 // units of 32 bins; two wavefronts fill one 16-byte cell (four bins x four frames) with 8 bytes each.  During the next
 // round wavefront w writes out, in iteration i, quarter i of the reader units w and w + 16.  The samples of an iteration
-// and the slot reads of its quarter are issued at the end of the iteration before.  The colour table is read from
-// global memory: the transforms use all of the CU's LDS.
+// and the slot reads of its quarter are issued at the end of the iteration before.
 #ifndef SONO_RF2048
 #define SONO_RF2048 128
 #endif
@@ -635,6 +634,10 @@ __global__ __launch_bounds__(kWaves * 64) void stft2048_rgba_kernel(StftParams p
     }
   };
   fetch(first_frame(0));
+  // The colour table: the transforms use all of the CU's LDS, but a wavefront's own transpose buffer is idle while it
+  // writes out its image quarter, so the table (1 KiB = 16 bytes per lane, kept in registers) is put there first and
+  // looked up through LDS instead of through the vector memory path.
+  const uint4 lut16 = reinterpret_cast<const uint4*>(p.lut)[lane];
   uint4 fq[kFPI][2] = {};
   // quarter j of iteration i: part and reader unit
   auto part_of = [](int i, int j) { return kFPI == 1 ? (i & 3) : i; };
@@ -654,9 +657,12 @@ __global__ __launch_bounds__(kWaves * 64) void stft2048_rgba_kernel(StftParams p
       if (round > 0) {
         const uint64_t frame0 = ((round - 1) * gridDim.x + vb) * kRF;
         if (frame0 < p.nframes) {
+          reinterpret_cast<uint4*>(fbuf)[lane] = lut16;
+          wave_sync();
 #pragma unroll
           for (int j = 0; j < kFPI; ++j)
-            rgba_flush::flush_quarter_store<kRF>(p, fq[j], p.lut, frame0, part_of(i, j), unit_of(i, j), lane);
+            rgba_flush::flush_quarter_store<kRF>(p, fq[j], reinterpret_cast<const uint32_t*>(fbuf), frame0, part_of(i, j), unit_of(i, j), lane);
+          wave_sync();  // (the transform rewrites the buffer)
         }
       }
     }
