@@ -253,9 +253,9 @@ __device__ __forceinline__ void transform2048(float (&re)[32], float (&im)[32], 
     }
     return;
   }
-  // Radix-2 stage across the lane pair (k1, k1 + 32).  Round 1: registers m and m + 16 trade halves, so the lower
+  // Radix-2 stage across the lane pair (k1, k1 + 32).  First swap: registers m and m + 16 trade halves, so the lower
   // lane holds y[m] (in re[m]) and y[m + 32] (in re[m + 16]) for m < 16 and the upper lane the same for
-  // m' = m + 16; sums and differences are taken in place.  Round 2: the sum register m and the difference register
+  // m' = m + 16; sums and differences are taken in place.  Second swap: the sum register m and the difference register
   // m + 16 trade halves again: the lower lane ends with all 32 differences, the upper lane with all 32 sums,
   // each as [values m < 16 | values m >= 16] = natural order.
 #pragma unroll
