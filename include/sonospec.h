@@ -330,7 +330,8 @@ int sono_get_config(const sono_ctx* ctx, sono_config* out);
 
 /* Launch on a caller-owned HIP stream (hipStream_t passed as void*); NULL restores the
  * context's own stream.  The new stream is made to wait (hipStreamWaitEvent, no host wait) for what the
- * context has already enqueued on the previous one: all launches of a context share its scratch. */
+ * context has already enqueued on the previous one: all launches of a context share its scratch.  A caller
+ * that destroys its stream restores the context's own (NULL) or sets another one before the next call. */
 int sono_set_stream(sono_ctx* ctx, void* hip_stream);
 
 /* Colour LUT used by SONO_OUT_RGBA8 and sono_colorize (what _colorMapUint / colorMapUint hold,

@@ -357,8 +357,11 @@ int sono_set_stream(sono_ctx* c, void* s) {
     // the context's scratch (image slots, index chunk, parked half transforms) is shared by all its launches: what
     // the new stream runs must not overtake what the previous one still has in flight
     HIP_TRY(c, hipSetDevice(c->device));
-    HIP_TRY(c, hipEventRecord(c->ev_switch, c->stream));
-    HIP_TRY(c, hipStreamWaitEvent(next, c->ev_switch, 0));
+    if (hipEventRecord(c->ev_switch, c->stream) == hipSuccess) {
+      HIP_TRY(c, hipStreamWaitEvent(next, c->ev_switch, 0));
+    } else {
+      (void)hipGetLastError();  // the previous stream is gone (its owner destroyed it): nothing of it is in flight
+    }
     c->stream = next;
   }
   return SONO_OK;
