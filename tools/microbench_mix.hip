@@ -72,10 +72,13 @@ __global__ __launch_bounds__(1024) void mix_kernel(const float* __restrict__ pcm
 int main(int argc, char** argv) {
   const uint64_t width = argc > 2 ? strtoull(argv[2], nullptr, 10) : 5399996ull;  // frames; default 1 h at 384 kHz, hop 256
   if (width < 128 || width > (1ull << 26)) { fprintf(stderr, "frames out of range\n"); return 1; }
-  // floor mode, optional: rows of the image (512; 1024 = the 2048-point writer), hop (256; 512), "slot" = the round's colour
-  // indices go through a global scratch slot as in the 2048-point writer
+  // floor mode, optional: rows of the image (512; 1024 = the 2048-point writer; 256 = the 512-point writer), hop (256; 512;
+  // 128), "slot" (or "-") = the round's colour indices go through a global scratch slot as in the 2048-point writer,
+  // frames per round (128; 256)
   const int rows = argc > 3 ? atoi(argv[3]) : 512, hop = argc > 4 ? atoi(argv[4]) : 256;
-  if ((rows != 512 && rows != 1024) || (hop != 256 && hop != 512)) { fprintf(stderr, "rows 512|1024, hop 256|512\n"); return 1; }
+  if ((rows != 256 && rows != 512 && rows != 1024) || (hop != 128 && hop != 256 && hop != 512)) { fprintf(stderr, "rows 256|512|1024, hop 128|256|512\n"); return 1; }
+  const int rf = argc > 6 ? atoi(argv[6]) : 128;  // frames per round: 128; 256 = the 512-point writer
+  if (rf != 128 && rf != 256) { fprintf(stderr, "round 128|256\n"); return 1; }
   const uint64_t img = width * 4 * rows, nsamp = width * hop + 4096;
   void* slots = nullptr;
   if (argc > 5 && std::string(argv[5]) == "slot") { CHECK(hipMalloc(&slots, (size_t)256 * 2 * rows * 128)); CHECK(hipMemset(slots, 0, (size_t)256 * 2 * rows * 128)); }
@@ -92,14 +95,18 @@ int main(int argc, char** argv) {
   if (argc > 1 && std::string(argv[1]) == "floor") {
     // one line for bench.py: the pattern the image writer uses (rounds of 128 frames, whole sectors, a contiguous range of
     // rounds per workgroup), writes alone, reads alone, both
-    const uint64_t nrounds = (width + 127) / 128;
+    const uint64_t nrounds = (width + rf - 1) / rf;
     float ms3[3];
     for (int rw = 0; rw < 3; ++rw) {
       float best = 1e30f;
       for (int rep = 0; rep < 4; ++rep) {
         CHECK(hipEventRecord(e0));
-        hipLaunchKernelGGL(mix_kernel<128>, dim3(256), dim3(1024), 0, 0, pcm, out, sink, width, nrounds, 0, 0, rw != 0, rw != 1, 1, rows, hop,
-                           (uint4*)(rw == 2 ? slots : nullptr));
+        if (rf == 128)
+          hipLaunchKernelGGL(mix_kernel<128>, dim3(256), dim3(1024), 0, 0, pcm, out, sink, width, nrounds, 0, 0, rw != 0, rw != 1, 1, rows, hop,
+                             (uint4*)(rw == 2 ? slots : nullptr));
+        else
+          hipLaunchKernelGGL(mix_kernel<256>, dim3(256), dim3(1024), 0, 0, pcm, out, sink, width, nrounds, 0, 0, rw != 0, rw != 1, 1, rows, hop,
+                             (uint4*)(rw == 2 ? slots : nullptr));
         CHECK(hipEventRecord(e1));
         CHECK(hipEventSynchronize(e1));
         float ms = 0;
@@ -108,8 +115,8 @@ int main(int argc, char** argv) {
       }
       ms3[rw] = best;
     }
-    printf("{\"frames\": %llu, \"rows\": %d, \"hop\": %d, \"slot\": %s, \"image_bytes\": %llu, \"sample_bytes\": %llu, \"writes_ms\": %.4f, \"reads_ms\": %.4f, \"both_ms\": %.4f}\n",
-           (unsigned long long)width, rows, hop, slots ? "true" : "false", (unsigned long long)img, (unsigned long long)(nsamp * 4), ms3[0], ms3[1], ms3[2]);
+    printf("{\"frames\": %llu, \"rows\": %d, \"hop\": %d, \"round_frames\": %d, \"slot\": %s, \"image_bytes\": %llu, \"sample_bytes\": %llu, \"writes_ms\": %.4f, \"reads_ms\": %.4f, \"both_ms\": %.4f}\n",
+           (unsigned long long)width, rows, hop, rf, slots ? "true" : "false", (unsigned long long)img, (unsigned long long)(nsamp * 4), ms3[0], ms3[1], ms3[2]);
     return 0;
   }
   printf("{\"image_gb\": %.3f, \"pcm_gb\": %.3f}\n", img / 1e9, nsamp * 4 / 1e9);
