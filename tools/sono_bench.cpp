@@ -40,6 +40,7 @@ int main(int argc, char** argv) {
   cfg.scale_mode = plugin ? SONO_SCALE_PLUGIN_DB : SONO_SCALE_WORKER_LOG5;
   cfg.frame_rule = plugin ? SONO_FRAMES_PLUGIN_STRICT : SONO_FRAMES_WORKER_COMPAT;
   cfg.twiddle_mode = plugin ? SONO_TW_PLUGIN_RECURRENCE : SONO_TW_ACCURATE;
+  if (getenv("SONO_BENCH_TW")) cfg.twiddle_mode = (uint32_t)atoi(getenv("SONO_BENCH_TW"));  // a SONO_TW_* id (A/B of the table flavours)
   cfg.arith = (argc > 9 && !strcmp(argv[9], "exact")) ? SONO_ARITH_EXACT_F64 : SONO_ARITH_FAST_F32;
   cfg.out_kind = rgba ? SONO_OUT_RGBA8 : feat ? SONO_OUT_FEATURES : SONO_OUT_U8_INDEX;
   if (argc > 8 && atoi(argv[8]) > 0) {
