@@ -34,6 +34,8 @@ def draw_config(rng):
     path = str(rng.choice(["worker", "plugin"]))
     if path == "worker":                                   # the worker derives its hop from a percentage
         hop = E.worker_hop(n, 100.0 * (1 - hop / n))
+    elif hop == n:                                         # the plugin cannot ask for it: noverlap 0 means "choose for me"
+        hop = n - 1                                        # (spectrogram.esm.js:502-506)
     out = str(rng.choice(["u8", "rgba", "features"]))
     frames = int(rng.choice([int(rng.integers(3, 40)), int(rng.integers(40, 700)), int(rng.integers(700, 1600))]))
     extra = int(rng.choice([0, int(rng.integers(0, hop))]))
@@ -85,7 +87,7 @@ def engine_of(c, out_kind):
 
 @pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("SONO_RANDOM_CASES", "96"))))
 def test_random_configuration_against_checker(seed):
-    rng = np.random.default_rng(1000 + seed)
+    rng = np.random.default_rng(int(__import__("os").environ.get("SONO_RANDOM_SEED0", "1000")) + seed)
     c = draw_config(rng)
     x = signal(rng, c["L"])
     if c["i16"]:
